@@ -1,0 +1,171 @@
+/*
+ * raytracer_amd.h -- C ABI of the MI355X ray-intersection engine (libraytracer_amd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of PaulThythy/raytracer: ray generation,
+ * acceleration-structure traversal and ray/primitive closest-hit + any-hit.  The reference has no
+ * FFI; the path is reached through four seams inside VkRenderer.  Every entry point
+ * below names the reference seam it replaces (paths relative to /root/reference).
+ *
+ * Conventions (mirroring the reference: single caller thread, blocking calls, owner keeps its arrays):
+ *   - return 0 on success, a negative RT_E_* code on failure; nothing is thrown across the ABI.
+ *     raytracer_amd/host/raytracer.hpp converts non-zero into std::runtime_error(rt_last_error()),
+ *     the reference's own convention (src/main.cpp:8-14).
+ *   - one caller thread per rt_ctx.  host_* buffers stay owned by the caller.
+ *   - *_dev entry points take DEVICE pointers valid on the context's device `slot` and enqueue on the
+ *     given hipStream_t (NULL = the slot's own stream); they do not synchronise.
+ *   - all arithmetic is fp32; hit records are bit-exact against oracle/ (see DESIGN.md).
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;   /* opaque; owns all device memory */
+
+/* shaders/frag.glsl:17-20 `struct Ray` plus an explicit interval (reference: tmin 0, tmax 1e20). */
+typedef struct { float ox, oy, oz, tmin, dx, dy, dz, tmax; } rt_ray;          /* 32 B */
+/* Result of shaders/frag.glsl:265-301 traceRay.  prim = index into the uploaded triangle array;
+ * bit 31 set = index into the sphere array; 0xFFFFFFFF = miss (then t = ray.tmax, u = v = 0). */
+typedef struct { float t, u, v; uint32_t prim; } rt_hit;                     /* 16 B */
+
+#define RT_MISS        0xFFFFFFFFu
+#define RT_SPHERE_BIT  0x80000000u
+
+enum {
+    RT_OK = 0,
+    RT_E_INVALID = -1,      /* bad argument (null pointer, wrong stride, zero size, ...) */
+    RT_E_DEVICE = -2,       /* HIP runtime error; text in rt_last_error */
+    RT_E_NO_SCENE = -3,     /* trace before rt_scene_upload */
+    RT_E_NO_CAMERA = -4,    /* primary rays before rt_set_camera */
+    RT_E_NOMEM = -5,
+    RT_E_TOO_LARGE = -6
+};
+
+/* rt_set_option keys */
+enum {
+    RT_OPT_TRAVERSAL = 1,   /* 0 auto (default), 1 brute force (the reference's loop), 2 BVH */
+    RT_OPT_BVH_THREADS = 2, /* host threads for the BVH build; 0 = hardware concurrency capped at 16 */
+    RT_OPT_COUNTERS = 3,    /* 1: *_dev closest-hit launches run the instrumented kernel and accumulate rt_counters */
+    RT_OPT_PAD_LOG2 = 4,    /* BVH boxes are padded by max|coordinate| * 2^-value (default 15); takes effect at upload */
+    RT_OPT_MAX_LEAF = 5     /* triangles per BVH leaf, 1..8 (default 4); takes effect at upload */
+};
+
+/* Scene / acceleration-structure statistics after rt_scene_upload. */
+typedef struct {
+    uint32_t n_tris, n_spheres, n_lights;
+    uint32_t n_nodes;          /* interior nodes of the flattened BVH */
+    uint32_t n_leaves;
+    uint32_t max_depth;
+    uint32_t node_bytes;       /* bytes per node in HBM */
+    uint32_t tri_bytes;        /* bytes per intersection triangle in HBM */
+    float    sah_cost;
+    float    build_ms;         /* host BVH build + flatten */
+    float    upload_ms;        /* H2D copies */
+    uint64_t device_bytes;     /* per replica */
+} rt_scene_stats;
+
+/* Work counters of the instrumented kernel (B, N, T per ray). */
+typedef struct {
+    uint64_t rays;
+    uint64_t box_tests;        /* B: child-box slab tests */
+    uint64_t nodes;            /* N: interior nodes fetched */
+    uint64_t tri_tests;        /* T: triangle tests */
+    uint64_t sphere_tests;
+} rt_counters;
+
+/* ---- life cycle --------------------------------------------------------------------------------
+ * Replaces VkRenderer::initVulkan's device pick + cleanupVulkan for the compute path
+ * (src/vulkan/VkRenderer.cpp:15-38, :40-122).  device_ids[i] are HIP device ordinals; each gets a
+ * replica of the scene ("slot" i).  n_devices >= 1; the same ordinal may appear more than once. */
+int  rt_create(rt_ctx** out, const int* device_ids, int n_devices);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);   /* never NULL; "" when the last call succeeded */
+int  rt_set_option(rt_ctx* ctx, int key, int64_t value);
+int  rt_num_slots(const rt_ctx* ctx);
+
+/* ---- scene upload (once) -----------------------------------------------------------------------
+ * Replaces VkRenderer::createData's three SSBO uploads (src/vulkan/VkRenderer.cpp:260-326).  Takes
+ * the reference's host structs as they are: Triangle 144 B (src/math/Triangle.h:10-15), Sphere 64 B
+ * (src/math/Sphere.h:10-15), Light 32 B (src/math/Light.h:6-10); strides must be >= those sizes and
+ * multiples of 4.  Counts are explicit: 0 means 0 (the reference uploads one zeroed element for an
+ * empty vector, :262-270; a zero triangle/sphere can never be hit, so results agree).
+ * Builds the BVH on the host, flattens it to the 16-B-aligned SoA layout of DESIGN.md and copies it
+ * to every slot.  The caller keeps its arrays. */
+int  rt_scene_upload(rt_ctx* ctx,
+                     const void* tris,    uint32_t n_tris,    uint32_t tri_stride,
+                     const void* spheres, uint32_t n_spheres, uint32_t sphere_stride,
+                     const void* lights,  uint32_t n_lights,  uint32_t light_stride);
+int  rt_scene_stats_get(const rt_ctx* ctx, rt_scene_stats* out);
+
+/* ---- camera (per frame) ------------------------------------------------------------------------
+ * Replaces VkRenderer::updateUniformBuffer (src/vulkan/VkRenderer.cpp:855-862): 112-byte
+ * Camera::UniformBufferObject (src/application/Camera.h:6-18). */
+int  rt_set_camera(rt_ctx* ctx, const void* camera_ubo112);
+
+/* ---- launch (per frame) ------------------------------------------------------------------------
+ * Replace the vkCmdDrawIndexed that runs frag.glsl:main once per pixel
+ * (src/vulkan/VkRenderer.cpp:1123), restricted to the intersection part of main().
+ * rt_trace_primary: getCameraRay with jitter off (frag.glsl:89-128) + traceRay (:265-301) for every
+ * pixel; uv = ((x+.5)/w, (y+.5)/h), row 0 = top (shaders/vert.glsl:9-12).  host_out[y*w+x]. */
+int  rt_trace_primary(rt_ctx* ctx, uint32_t w, uint32_t h, rt_hit* host_out);
+/* closest hit for caller-supplied rays (frag.glsl:265-301).  Rays are split in contiguous ranges
+ * over the slots. */
+int  rt_trace(rt_ctx* ctx, const rt_ray* host_rays, uint64_t n, rt_hit* host_out);
+/* any-hit: host_out[i] = 1 iff some primitive is hit with tmin <= t < tmax.  The reference has no
+ * any-hit routine; its shadow query (frag.glsl:325-330) is rt_shadow_dev. */
+int  rt_occluded(rt_ctx* ctx, const rt_ray* host_rays, uint64_t n, uint8_t* host_out);
+
+/* ---- device-resident pipeline stages (inputs/outputs stay in HBM) ------------------------------ */
+/* Primary rays for the pixel rows [y0, y0+rows) of a w x h image, spp samples per pixel, and their
+ * closest hits.  jitter != 0 applies frag.glsl:94-103 with the seeded hash of DESIGN.md instead of
+ * frag.glsl:13-15.  Ray index r = ((y-y0)*w + x)*spp + s; RNG key uses the full-image index.
+ * d_rays_out may be NULL when the rays themselves are not needed. */
+int  rt_trace_primary_dev(rt_ctx* ctx, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+                          uint32_t spp, uint32_t seed, int jitter,
+                          rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream);
+/* Same, for an interleaved share of the image: local row yl maps to image row
+ * y0 + (yl / stripe_h) * stripe_h * stripe_step + yl % stripe_h (rows beyond h are skipped), so rank r
+ * of N takes y0 = r*stripe_h, stripe_step = N.  stripe_h should be a multiple of 8 (tile height).
+ * Output index ((yl*w + x)*spp + s) is compact in the local rows. */
+int  rt_trace_primary_stripes_dev(rt_ctx* ctx, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+                                  uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t seed, int jitter,
+                                  rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream);
+int  rt_trace_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits_out, void* stream);
+int  rt_occluded_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, uint64_t n, uint8_t* d_out, void* stream);
+/* frag.glsl:321-330 for one light: from (rays, hits) build the shadow ray at p + N*0.001 towards
+ * light_pos, trace closest-hit, d_lit[i] = 1 lit / 0 shadowed / 2 primary miss.
+ * d_shadow_rays_out may be NULL. */
+int  rt_shadow_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                   const float light_pos[3], rt_ray* d_shadow_rays_out, uint8_t* d_lit, void* stream);
+/* frag.glsl:185-203 + :340-343: cosine-weighted bounce rays from hits (key0 = RNG key of element 0). */
+int  rt_bounce_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                   uint32_t key0, uint32_t seed, rt_ray* d_rays_out, void* stream);
+
+int  rt_counters_get(rt_ctx* ctx, int slot, rt_counters* out, int reset);
+int  rt_sync(rt_ctx* ctx, int slot);
+
+/* ---- scene generators (host) -------------------------------------------------------------------
+ * The reference compiles its scene into VkRenderer::createData (src/vulkan/VkRenderer.cpp:164-258)
+ * and has one tessellator, Sphere::sphereGeometry (src/math/Sphere.h:17-79).  These write arrays of
+ * the reference's 144-B Triangle / 64-B Sphere structs.  Each returns the number of elements the
+ * scene has; it writes at most `cap` of them (call with cap = 0 to size). */
+uint32_t rt_gen_cornell_triangles(void* tris144, uint32_t cap);               /* 12, VkRenderer.cpp:171-238 */
+uint32_t rt_gen_cornell_spheres(void* spheres64, uint32_t cap);               /* 3,  VkRenderer.cpp:240-250 */
+uint32_t rt_gen_sphere_geometry(const float center[3], float radius, uint32_t stacks, uint32_t slices,
+                                const float material12[12], void* tris144, uint32_t cap); /* Sphere.h:17-79 */
+uint32_t rt_gen_soup(uint64_t seed, uint32_t n, float half_extent, void* tris144, uint32_t cap); /* SURVEY C4 */
+void     rt_gen_random_rays(uint64_t seed, uint64_t first, uint64_t n, rt_ray* out);              /* SURVEY C4 */
+/* Default camera of VkRenderer::VkRenderer (src/vulkan/VkRenderer.cpp:3-12) with the basis of
+ * Camera::updateCameraVectors (src/application/Camera.h:36-41). */
+void     rt_camera_look_at(const float pos[3], const float look_at[3], float fov_deg, float aspect,
+                           void* camera_ubo112);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

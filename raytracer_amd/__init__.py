@@ -1,0 +1,210 @@
+"""raytracer_amd -- MI355X-native ray-intersection engine for the PaulThythy/raytracer hot path.
+
+Host-side mirror of the reference's renderer seams (src/vulkan/VkRenderer.cpp: createData :164-327,
+updateUniformBuffer :855-862, the draw at :1123) over the C ABI in include/raytracer_amd.h.  The
+compute lives in raytracer_amd/csrc (hand-written HIP for gfx950); this package is plumbing.
+Errors follow the reference's convention (std::runtime_error caught in main, src/main.cpp:8-14):
+any non-zero ABI return raises RuntimeError(rt_last_error()).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import rt_counters, rt_scene_stats
+
+__all__ = ["Renderer", "TRIANGLE", "SPHERE", "LIGHT", "CAMERA", "RAY", "HIT", "MATERIAL", "VERTEX",
+           "MISS", "SPHERE_BIT", "camera_look_at", "default_camera", "lib"]
+
+MISS = 0xFFFFFFFF
+SPHERE_BIT = 0x80000000
+
+# numpy twins of the reference's host structs (byte layouts: raytracer_amd/host/rt_types.hpp)
+VERTEX = np.dtype({"names": ["position", "normal"], "formats": ["3f4", "3f4"], "offsets": [0, 16], "itemsize": 32})
+MATERIAL = np.dtype({"names": ["albedo", "emission", "emissionStrength", "roughness", "metallic"],
+                     "formats": ["3f4", "3f4", "f4", "f4", "f4"], "offsets": [0, 16, 28, 32, 36], "itemsize": 48})
+TRIANGLE = np.dtype({"names": ["v0", "v1", "v2", "material"], "formats": [VERTEX, VERTEX, VERTEX, MATERIAL],
+                     "offsets": [0, 32, 64, 96], "itemsize": 144})
+SPHERE = np.dtype({"names": ["center", "radius", "material"], "formats": ["3f4", "f4", MATERIAL],
+                   "offsets": [0, 12, 16], "itemsize": 64})
+LIGHT = np.dtype({"names": ["position", "color", "intensity"], "formats": ["3f4", "3f4", "f4"],
+                  "offsets": [0, 16, 28], "itemsize": 32})
+CAMERA = np.dtype({"names": ["position", "lookAt", "front", "up", "right", "worldUp", "fov", "aspectRatio",
+                             "nearPlane", "farPlane"],
+                   "formats": ["3f4"] * 6 + ["f4"] * 4, "offsets": [0, 16, 32, 48, 64, 80, 92, 96, 100, 104],
+                   "itemsize": 112})
+RAY = np.dtype([("o", "3f4"), ("tmin", "f4"), ("d", "3f4"), ("tmax", "f4")])
+HIT = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("prim", "u4")])
+assert RAY.itemsize == 32 and HIT.itemsize == 16
+
+OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF = 1, 2, 3, 4, 5
+TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH = 0, 1, 2
+
+
+def lib():
+    return _abi.load()
+
+
+def _ptr(x):
+    """Raw address of a numpy array, a torch tensor (data_ptr) or an int; None -> NULL."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"cannot take the address of {type(x)}")
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)      # torch.cuda.Stream
+
+
+def camera_look_at(pos, look_at, fov_deg, aspect):
+    """Camera::Camera + updateCameraVectors (src/application/Camera.h:24-41) -> 112-byte UBO record."""
+    ubo = np.zeros(1, dtype=CAMERA)
+    p = (C.c_float * 3)(*pos)
+    l = (C.c_float * 3)(*look_at)
+    lib().rt_camera_look_at(p, l, C.c_float(fov_deg), C.c_float(aspect), _ptr(ubo))
+    return ubo
+
+
+def default_camera(aspect=1200.0 / 1000.0):
+    """VkRenderer::VkRenderer (src/vulkan/VkRenderer.cpp:3-12)."""
+    return camera_look_at((0.0, 4.0, 1.0), (0.0, 0.0, 1.0), 45.0, aspect)
+
+
+class Renderer:
+    """Owner of an rt_ctx: the compute-side stand-in for VkRenderer's scene/camera/draw seams."""
+
+    def __init__(self, device_ids=(0,)):
+        self._lib = lib()
+        self._ctx = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        rc = self._lib.rt_create(C.byref(self._ctx), ids, len(device_ids))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise RuntimeError(f"rt_create failed ({rc}): no usable HIP device or bad device id")
+        self._keep = None
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"{self._lib.rt_last_error(self._ctx).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def num_slots(self):
+        return self._lib.rt_num_slots(self._ctx)
+
+    def set_option(self, key, value):
+        self._check(self._lib.rt_set_option(self._ctx, key, int(value)))
+
+    # -- createData (src/vulkan/VkRenderer.cpp:164-327) --------------------------------------------
+    def create_data(self, triangles=None, spheres=None, lights=None):
+        def prep(a, dt):
+            if a is None:
+                return np.zeros(0, dtype=dt)
+            a = np.ascontiguousarray(a)
+            if a.dtype != dt:
+                raise RuntimeError(f"expected dtype with itemsize {dt.itemsize}, got {a.dtype}")
+            return a
+        t, s, l = prep(triangles, TRIANGLE), prep(spheres, SPHERE), prep(lights, LIGHT)
+        self._check(self._lib.rt_scene_upload(self._ctx, _ptr(t) if len(t) else None, len(t), TRIANGLE.itemsize,
+                                              _ptr(s) if len(s) else None, len(s), SPHERE.itemsize,
+                                              _ptr(l) if len(l) else None, len(l), LIGHT.itemsize))
+        return self.scene_stats()
+
+    def scene_stats(self):
+        st = rt_scene_stats()
+        self._check(self._lib.rt_scene_stats_get(self._ctx, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    # -- updateUniformBuffer (src/vulkan/VkRenderer.cpp:855-862) -----------------------------------
+    def update_camera(self, ubo):
+        ubo = np.ascontiguousarray(ubo)
+        if ubo.nbytes != 112:
+            raise RuntimeError("camera UBO must be 112 bytes")
+        self._check(self._lib.rt_set_camera(self._ctx, _ptr(ubo)))
+
+    # -- the draw (src/vulkan/VkRenderer.cpp:1123), host buffers ------------------------------------
+    def trace_primary(self, w, h):
+        out = np.empty(w * h, dtype=HIT)
+        self._check(self._lib.rt_trace_primary(self._ctx, w, h, _ptr(out)))
+        return out.reshape(h, w)
+
+    def trace(self, rays):
+        rays = np.ascontiguousarray(rays)
+        if rays.dtype != RAY:
+            raise RuntimeError("rays must have dtype RAY (32 B)")
+        out = np.empty(len(rays), dtype=HIT)
+        self._check(self._lib.rt_trace(self._ctx, _ptr(rays) if len(rays) else None, len(rays),
+                                       _ptr(out) if len(rays) else None))
+        return out
+
+    def occluded(self, rays):
+        rays = np.ascontiguousarray(rays)
+        if rays.dtype != RAY:
+            raise RuntimeError("rays must have dtype RAY (32 B)")
+        out = np.empty(len(rays), dtype=np.uint8)
+        self._check(self._lib.rt_occluded(self._ctx, _ptr(rays) if len(rays) else None, len(rays),
+                                          _ptr(out) if len(rays) else None))
+        return out
+
+    # -- device-resident stages (pointers: torch tensors on the slot's device, or raw ints) ---------
+    def trace_primary_dev(self, w, h, hits, rays=None, y0=0, rows=None, spp=1, seed=0, jitter=False, slot=0,
+                          stream=None):
+        rows = h - y0 if rows is None else rows
+        self._check(self._lib.rt_trace_primary_dev(self._ctx, slot, w, h, y0, rows, spp, seed, int(bool(jitter)),
+                                                   _ptr(rays), _ptr(hits), _stream_ptr(stream)))
+
+    def trace_primary_stripes_dev(self, w, h, y0, rows, stripe_h, stripe_step, hits, rays=None, spp=1, seed=0,
+                                  jitter=False, slot=0, stream=None):
+        self._check(self._lib.rt_trace_primary_stripes_dev(self._ctx, slot, w, h, y0, rows, stripe_h, stripe_step,
+                                                           spp, seed, int(bool(jitter)), _ptr(rays), _ptr(hits),
+                                                           _stream_ptr(stream)))
+
+    def trace_dev(self, rays, n, hits, slot=0, stream=None):
+        self._check(self._lib.rt_trace_dev(self._ctx, slot, _ptr(rays), n, _ptr(hits), _stream_ptr(stream)))
+
+    def occluded_dev(self, rays, n, out, slot=0, stream=None):
+        self._check(self._lib.rt_occluded_dev(self._ctx, slot, _ptr(rays), n, _ptr(out), _stream_ptr(stream)))
+
+    def shadow_dev(self, rays, hits, n, light_pos, lit, shadow_rays=None, slot=0, stream=None):
+        lp = (C.c_float * 3)(*light_pos)
+        self._check(self._lib.rt_shadow_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, lp, _ptr(shadow_rays),
+                                            _ptr(lit), _stream_ptr(stream)))
+
+    def bounce_dev(self, rays, hits, n, out_rays, key0=0, seed=0, slot=0, stream=None):
+        self._check(self._lib.rt_bounce_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, key0, seed, _ptr(out_rays),
+                                            _stream_ptr(stream)))
+
+    def counters(self, slot=0, reset=True):
+        c = rt_counters()
+        self._check(self._lib.rt_counters_get(self._ctx, slot, C.byref(c), int(reset)))
+        return {f: getattr(c, f) for f, _ in c._fields_}
+
+    def sync(self, slot=0):
+        self._check(self._lib.rt_sync(self._ctx, slot))

@@ -1,0 +1,66 @@
+// bvh.hpp -- host-side acceleration-structure build for the MI355X ray engine.
+//
+// Build-original: the reference has no acceleration structure (shaders/frag.glsl:265-301 is a linear
+// loop over every primitive).  The correctness contract is "return exactly what that loop returns"
+// (consequence 2); DESIGN.md explains how boxes are padded so that traversal
+// never culls the primitive the loop would have chosen.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace rt {
+
+struct Aabb {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; } }
+    void grow(const Aabb& b) { for (int a = 0; a < 3; ++a) { if (b.lo[a] < lo[a]) lo[a] = b.lo[a]; if (b.hi[a] > hi[a]) hi[a] = b.hi[a]; } }
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { if (p[a] < lo[a]) lo[a] = p[a]; if (p[a] > hi[a]) hi[a] = p[a]; } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+// Binary build tree.  count > 0 => leaf over prim_index[first, first+count).
+struct BuildNode {
+    Aabb box;
+    uint32_t left = 0, right = 0;
+    uint32_t first = 0, count = 0;
+};
+
+struct BuildParams {
+    int   max_leaf = 4;       // primitives per leaf (<= 8: leaf references carry a 3-bit count)
+    int   max_depth = 30;     // leaves sit at depth <= max_depth (root = 0); bounds the traversal stack
+    float cost_trav = 1.2f;   // SAH: one interior step
+    float cost_isect = 1.0f;  // SAH: one triangle test
+    int   threads = 0;        // 0 = hardware concurrency, capped at 16
+};
+
+struct BuildResult {
+    std::vector<BuildNode> nodes;      // nodes[0] = root
+    std::vector<uint32_t>  prim_index; // permutation of [0, n)
+    uint32_t depth = 0;
+    uint32_t n_leaves = 0;
+    float    sah_cost = 0.f;
+};
+
+// prim_boxes: n exact (unpadded) primitive bounds.
+void build_bvh2(const Aabb* prim_boxes, uint32_t n, const BuildParams& p, BuildResult& out);
+
+// ---- flattened HBM layout (see DESIGN.md "Data layout") ---------------------------------------
+// Interior node, 64 B = 4 x float4 (16-B aligned SoA of the two children):
+//   q0 = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)
+//   q1 = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//   q2 = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+//   q3 = (bits child0, bits child1, 0, 0)
+// child reference: >= 0 interior node index; < 0 leaf: ~ref = (first_tri << 3) | (count - 1).
+struct FlatBvh2 {
+    std::vector<float>    nodes;      // 16 floats per interior node
+    std::vector<uint32_t> tri_order;  // tri_order[k] = original triangle index stored at slot k
+    uint32_t n_nodes = 0, n_leaves = 0, depth = 0;
+};
+static constexpr int32_t kEmptyLeaf = 0x7fffffff;   // never visited: its box is inverted
+
+void flatten_bvh2(const BuildResult& b, float pad, FlatBvh2& out);
+
+}  // namespace rt

@@ -1,0 +1,46 @@
+// kernels.hpp -- launch interface between the C ABI (rt_api.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include "../../include/raytracer_amd.h"
+
+namespace rt {
+
+// Device view of one scene replica (all pointers 16-B aligned, see DESIGN.md "Data layout").
+struct DevScene {
+    const float4* nodes;     // 4 x float4 per interior node (BVH2)
+    const float4* tris;      // 3 x float4 per triangle in leaf order: (v0, bits id) (e1, 0) (e2, 0)
+    const float4* normals;   // 3 x float4 per triangle in ORIGINAL order: n0, n1, n2
+    const float4* spheres;   // (centre, radius)
+    uint32_t n_nodes, n_tris, n_spheres, stack_depth;
+};
+
+// Camera constants precomputed on the host by rt_set_camera (frag.glsl:106-110: tan of the half fov
+// is evaluated with the host libm so that kernel and oracle see the same bits).
+struct DevCamera {
+    float px, py, pz, half_w;
+    float rx, ry, rz, half_h;
+    float ux, uy, uz, pad0;
+    float fx, fy, fz, pad1;
+};
+
+enum TraceMode { kBrute = 1, kBvh2 = 2 };
+
+hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
+                        rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st);
+
+hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, bool count, uint32_t w, uint32_t h,
+                          uint32_t y0, uint32_t rows, uint32_t stripe_h, uint32_t stripe_step, uint32_t spp,
+                          uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits,
+                          unsigned long long* d_counters, hipStream_t st);
+
+hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                         float lx, float ly, float lz, rt_ray* d_shadow_rays, uint8_t* d_lit, hipStream_t st);
+
+hipError_t launch_bounce(const DevScene& s, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
+                         uint32_t seed, rt_ray* d_out, hipStream_t st);
+
+constexpr int kStackDepth = 32;   // per-lane traversal stack entries held in LDS
+constexpr int kNumCounters = 5;   // rays, box_tests, nodes, tri_tests, sphere_tests
+
+}  // namespace rt

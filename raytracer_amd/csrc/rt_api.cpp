@@ -1,0 +1,498 @@
+// rt_api.cpp -- implementation of the C ABI declared in include/raytracer_amd.h.
+//
+// Host-side orchestration only: argument checks, BVH build + flatten, HBM replicas, chunked
+// H2D/D2H for the host-pointer entry points, and kernel launches (kernels.hip).  Seams replaced in the
+// reference are cited next to each declaration in the header.
+#include "../../include/raytracer_amd.h"
+#include "../host/rt_types.hpp"
+#include "bvh.hpp"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace rt;
+
+namespace {
+
+constexpr uint64_t kChunkRays = 1ull << 22;   // host-pointer entry points stream rays in 4 Mi-ray pieces
+
+struct Replica {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    float4* d_normals = nullptr;
+    float4* d_spheres = nullptr;
+    unsigned long long* d_counters = nullptr;
+    // scratch for host-pointer entry points
+    void* d_rays = nullptr;  size_t rays_cap = 0;
+    void* d_out = nullptr;   size_t out_cap = 0;
+    std::string err;
+};
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct rt_ctx {
+    std::vector<Replica> reps;
+    std::string err;
+    // options
+    int traversal = 0;          // 0 auto, 1 brute, 2 bvh
+    int bvh_threads = 0;
+    int counters = 0;
+    int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2
+    int max_leaf = 4;
+    // scene
+    bool has_scene = false, has_camera = false;
+    rt_scene_stats stats{};
+    DevCamera cam{};
+    int mode() const {
+        if (traversal == 1) return kBrute;
+        if (traversal == 2) return kBvh2;
+        return stats.n_tris <= 32 ? kBrute : kBvh2;
+    }
+    DevScene dev_scene(const Replica& r) const {
+        DevScene s;
+        s.nodes = r.d_nodes; s.tris = r.d_tris; s.normals = r.d_normals; s.spheres = r.d_spheres;
+        s.n_nodes = stats.n_nodes; s.n_tris = stats.n_tris; s.n_spheres = stats.n_spheres;
+        s.stack_depth = stats.max_depth;
+        return s;
+    }
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int fail_hip(rt_ctx* c, hipError_t e, const char* what) {
+    return fail(c, RT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RT_HIP(ctx, call)                                              \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);     \
+    } while (0)
+
+void free_scene(Replica& r) {
+    hipSetDevice(r.device);
+    if (r.d_nodes) hipFree(r.d_nodes);
+    if (r.d_tris) hipFree(r.d_tris);
+    if (r.d_normals) hipFree(r.d_normals);
+    if (r.d_spheres) hipFree(r.d_spheres);
+    r.d_nodes = r.d_tris = r.d_normals = r.d_spheres = nullptr;
+}
+
+bool valid_slot(const rt_ctx* c, int slot) { return c && slot >= 0 && slot < (int)c->reps.size(); }
+
+// Run fn(slot) on every replica; one host thread per replica when there are several (they drive
+// different devices, and pageable-memory copies block the calling thread).
+template <class F>
+int for_each_slot(rt_ctx* c, F fn) {
+    const int n = (int)c->reps.size();
+    std::vector<int> rc(n, RT_OK);
+    if (n == 1) {
+        rc[0] = fn(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int s = 0; s < n; ++s) th.emplace_back([&, s] { rc[s] = fn(s); });
+        for (auto& t : th) t.join();
+    }
+    for (int s = 0; s < n; ++s)
+        if (rc[s] != RT_OK) { c->err = c->reps[s].err; return rc[s]; }
+    return RT_OK;
+}
+
+int slot_fail(Replica& r, hipError_t e, const char* what) {
+    r.err = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_E_DEVICE;
+}
+#define RT_HIP_SLOT(r, call)                                           \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return slot_fail((r), e__, #call);      \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
+    if (!out) return RT_E_INVALID;
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return RT_E_INVALID;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return RT_E_DEVICE;
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return RT_E_NOMEM;
+    c->reps.resize(n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        int d = device_ids ? device_ids[i] : i;
+        if (d < 0 || d >= ndev) { delete c; return RT_E_INVALID; }
+        Replica& r = c->reps[i];
+        r.device = d;
+        if (hipSetDevice(d) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(&r.d_counters, kNumCounters * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(r.d_counters, 0, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
+            rt_destroy(c);
+            return RT_E_DEVICE;
+        }
+    }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    for (Replica& r : c->reps) {
+        hipSetDevice(r.device);
+        if (r.stream) hipStreamSynchronize(r.stream);
+        free_scene(r);
+        if (r.d_counters) hipFree(r.d_counters);
+        if (r.d_rays) hipFree(r.d_rays);
+        if (r.d_out) hipFree(r.d_out);
+        if (r.stream) hipStreamDestroy(r.stream);
+    }
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_num_slots(const rt_ctx* c) { return c ? (int)c->reps.size() : 0; }
+
+int rt_set_option(rt_ctx* c, int key, int64_t v) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    switch (key) {
+        case RT_OPT_TRAVERSAL:   if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_TRAVERSAL: 0 auto, 1 brute, 2 bvh"); c->traversal = (int)v; return RT_OK;
+        case RT_OPT_BVH_THREADS: if (v < 0 || v > 256) return fail(c, RT_E_INVALID, "RT_OPT_BVH_THREADS out of range"); c->bvh_threads = (int)v; return RT_OK;
+        case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
+        case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
+        case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;
+        default: return fail(c, RT_E_INVALID, "unknown option key");
+    }
+}
+
+int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_stride, const void* spheres,
+                    uint32_t n_spheres, uint32_t sphere_stride, const void* lights, uint32_t n_lights,
+                    uint32_t light_stride) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (n_tris && (!tris || tri_stride < sizeof(Triangle) || (tri_stride & 3))) return fail(c, RT_E_INVALID, "triangles: null pointer or stride < 144 / not a multiple of 4");
+    if (n_spheres && (!spheres || sphere_stride < sizeof(Sphere) || (sphere_stride & 3))) return fail(c, RT_E_INVALID, "spheres: null pointer or stride < 64 / not a multiple of 4");
+    if (n_lights && (!lights || light_stride < sizeof(Light) || (light_stride & 3))) return fail(c, RT_E_INVALID, "lights: null pointer or stride < 32 / not a multiple of 4");
+    if (n_tris >= (1u << 28)) return fail(c, RT_E_TOO_LARGE, "more than 2^28-1 triangles");
+    if (n_spheres >= (1u << 31)) return fail(c, RT_E_TOO_LARGE, "more than 2^31-1 spheres");
+
+    const double t0 = now_ms();
+    // 1. exact triangle bounds (positions at byte offsets 0 / 32 / 64 of the 144-B struct)
+    std::vector<Aabb> boxes(n_tris);
+    float maxabs = 0.f;
+    const char* tb = static_cast<const char*>(tris);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const char* t = tb + (size_t)i * tri_stride;
+        Aabb b; b.reset();
+        for (int v = 0; v < 3; ++v) {
+            float p[3];
+            std::memcpy(p, t + 32 * v, 12);
+            for (int a = 0; a < 3; ++a) {
+                if (!std::isfinite(p[a])) return fail(c, RT_E_INVALID, "triangle " + std::to_string(i) + " has a non-finite position");
+                maxabs = std::max(maxabs, std::fabs(p[a]));
+            }
+            b.grow(p);
+        }
+        boxes[i] = b;
+    }
+    // 2. BVH2 build + flatten
+    BuildParams bp;
+    bp.max_leaf = c->max_leaf;
+    bp.max_depth = kStackDepth - 2;
+    bp.threads = c->bvh_threads;
+    BuildResult br;
+    build_bvh2(boxes.data(), n_tris, bp, br);
+    for (const BuildNode& nd : br.nodes)
+        if (nd.count > 8) return fail(c, RT_E_TOO_LARGE, "internal: leaf with more than 8 triangles (depth budget exceeded)");
+    FlatBvh2 flat;
+    const float pad = std::ldexp(std::max(maxabs, 1e-30f), -c->pad_log2);
+    flatten_bvh2(br, n_tris ? pad : 0.f, flat);
+    if (flat.depth + 1 > (uint32_t)kStackDepth) return fail(c, RT_E_TOO_LARGE, "internal: BVH deeper than the traversal stack");
+
+    // 3. device records
+    std::vector<float> tri48((size_t)n_tris * 12), nrm48((size_t)n_tris * 12), sph((size_t)n_spheres * 4);
+    for (uint32_t k = 0; k < n_tris; ++k) {
+        const uint32_t id = flat.tri_order[k];
+        const char* t = tb + (size_t)id * tri_stride;
+        float p0[3], p1[3], p2[3];
+        std::memcpy(p0, t, 12); std::memcpy(p1, t + 32, 12); std::memcpy(p2, t + 64, 12);
+        float* o = &tri48[(size_t)k * 12];
+        o[0] = p0[0]; o[1] = p0[1]; o[2] = p0[2]; std::memcpy(&o[3], &id, 4);
+        // frag.glsl:132-133: edge1 = v1 - v0, edge2 = v2 - v0 (plain fp32 subtraction, no contraction possible)
+        o[4] = p1[0] - p0[0]; o[5] = p1[1] - p0[1]; o[6] = p1[2] - p0[2]; o[7] = 0.f;
+        o[8] = p2[0] - p0[0]; o[9] = p2[1] - p0[1]; o[10] = p2[2] - p0[2]; o[11] = 0.f;
+    }
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const char* t = tb + (size_t)i * tri_stride;
+        float* o = &nrm48[(size_t)i * 12];
+        for (int v = 0; v < 3; ++v) { std::memcpy(o + 4 * v, t + 16 + 32 * v, 12); o[4 * v + 3] = 0.f; }
+    }
+    const char* sb = static_cast<const char*>(spheres);
+    for (uint32_t i = 0; i < n_spheres; ++i) std::memcpy(&sph[(size_t)i * 4], sb + (size_t)i * sphere_stride, 16);
+    const double t1 = now_ms();
+
+    // 4. replicate
+    c->has_scene = false;
+    for (Replica& r : c->reps) {
+        RT_HIP(c, hipSetDevice(r.device));
+        RT_HIP(c, hipStreamSynchronize(r.stream));
+        free_scene(r);
+        auto up = [&](float4** dst, const std::vector<float>& src) -> hipError_t {
+            const size_t bytes = std::max<size_t>(src.size() * sizeof(float), 64);
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), bytes);
+            if (e != hipSuccess) return e;
+            e = hipMemset(*dst, 0, bytes);
+            if (e != hipSuccess || src.empty()) return e;
+            return hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
+        };
+        RT_HIP(c, up(&r.d_nodes, flat.nodes));
+        RT_HIP(c, up(&r.d_tris, tri48));
+        RT_HIP(c, up(&r.d_normals, nrm48));
+        RT_HIP(c, up(&r.d_spheres, sph));
+    }
+    const double t2 = now_ms();
+
+    rt_scene_stats& st = c->stats;
+    st = rt_scene_stats{};
+    st.n_tris = n_tris; st.n_spheres = n_spheres; st.n_lights = n_lights;
+    st.n_nodes = flat.n_nodes; st.n_leaves = flat.n_leaves; st.max_depth = flat.depth;
+    st.node_bytes = 64; st.tri_bytes = 48;
+    st.sah_cost = br.sah_cost;
+    st.build_ms = (float)(t1 - t0); st.upload_ms = (float)(t2 - t1);
+    st.device_bytes = (uint64_t)flat.nodes.size() * 4 + (uint64_t)tri48.size() * 4 + (uint64_t)nrm48.size() * 4 + (uint64_t)sph.size() * 4;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+int rt_scene_stats_get(const rt_ctx* c, rt_scene_stats* out) {
+    if (!c || !out) return RT_E_INVALID;
+    if (!c->has_scene) return RT_E_NO_SCENE;
+    *out = c->stats;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* c, const void* ubo) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!ubo) return fail(c, RT_E_INVALID, "camera: null pointer");
+    CameraUBO u;
+    std::memcpy(&u, ubo, sizeof u);
+    DevCamera d{};
+    d.px = u.m_position.x; d.py = u.m_position.y; d.pz = u.m_position.z;
+    d.rx = u.m_right.x; d.ry = u.m_right.y; d.rz = u.m_right.z;
+    d.ux = u.m_up.x; d.uy = u.m_up.y; d.uz = u.m_up.z;
+    d.fx = u.m_front.x; d.fy = u.m_front.y; d.fz = u.m_front.z;
+    // frag.glsl:106-110.  radians() = deg * pi/180 in fp32; tan from the host libm.
+    const float fov = u.m_fov * 0.017453292519943295f;
+    d.half_h = tanf(fov / 2.0f);
+    d.half_w = d.half_h * u.m_aspectRatio;
+    c->cam = d;
+    c->has_camera = true;
+    return RT_OK;
+}
+
+// ---- device-resident stages -------------------------------------------------------------------------
+static int check_stage(rt_ctx* c, int slot, bool need_cam) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
+    if (!c->has_scene) return fail(c, RT_E_NO_SCENE, "no scene uploaded");
+    if (need_cam && !c->has_camera) return fail(c, RT_E_NO_CAMERA, "no camera set");
+    return RT_OK;
+}
+
+int rt_trace_primary_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+                                 uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t seed, int jitter,
+                                 rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) {
+    int rc = check_stage(c, slot, true);
+    if (rc) return rc;
+    if (!d_hits_out || w == 0 || h == 0 || spp == 0 || stripe_h == 0 || stripe_step == 0) return fail(c, RT_E_INVALID, "primary: bad arguments");
+    if ((uint64_t)w * h * spp > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "primary: w*h*spp exceeds 2^32-1 (RNG key width)");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), c->counters != 0, w, h, y0, rows, stripe_h, stripe_step,
+                             spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st));
+    return RT_OK;
+}
+
+int rt_trace_primary_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows, uint32_t spp,
+                         uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) {
+    if (c && (uint64_t)y0 + rows > h) return fail(c, RT_E_INVALID, "primary: y0 + rows > h");
+    return rt_trace_primary_stripes_dev(c, slot, w, h, y0, rows, rows ? rows : 1, 1, spp, seed, jitter, d_rays_out, d_hits_out, stream);
+}
+
+int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits, void* stream) {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (n && (!d_rays || !d_hits)) return fail(c, RT_E_INVALID, "trace: null device pointer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), false, c->counters != 0, d_rays, n, d_hits, nullptr, r.d_counters, st));
+    return RT_OK;
+}
+
+int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8_t* d_out, void* stream) {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (n && (!d_rays || !d_out)) return fail(c, RT_E_INVALID, "occluded: null device pointer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), true, false, d_rays, n, nullptr, d_out, r.d_counters, st));
+    return RT_OK;
+}
+
+int rt_shadow_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, const float lp[3],
+                  rt_ray* d_srays, uint8_t* d_lit, void* stream) {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (!lp || (n && (!d_rays || !d_hits || !d_lit))) return fail(c, RT_E_INVALID, "shadow: null pointer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    RT_HIP(c, launch_shadow(c->dev_scene(r), c->mode(), d_rays, d_hits, n, lp[0], lp[1], lp[2], d_srays, d_lit, st));
+    return RT_OK;
+}
+
+int rt_bounce_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
+                  uint32_t seed, rt_ray* d_out, void* stream) {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (n && (!d_rays || !d_hits || !d_out)) return fail(c, RT_E_INVALID, "bounce: null device pointer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    RT_HIP(c, launch_bounce(c->dev_scene(r), d_rays, d_hits, n, key0, seed, d_out, st));
+    return RT_OK;
+}
+
+int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) {
+    if (!c || !out) return RT_E_INVALID;
+    c->err.clear();
+    if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    RT_HIP(c, hipDeviceSynchronize());
+    unsigned long long v[kNumCounters];
+    RT_HIP(c, hipMemcpy(v, r.d_counters, sizeof v, hipMemcpyDeviceToHost));
+    out->rays = v[0]; out->box_tests = v[1]; out->nodes = v[2]; out->tri_tests = v[3]; out->sphere_tests = v[4];
+    if (reset) RT_HIP(c, hipMemset(r.d_counters, 0, sizeof v));
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* c, int slot) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
+    RT_HIP(c, hipSetDevice(c->reps[slot].device));
+    RT_HIP(c, hipStreamSynchronize(c->reps[slot].stream));
+    return RT_OK;
+}
+
+// ---- host-pointer entry points (blocking; what the reference's single-threaded frame loop expects) ---
+int rt_trace_primary(rt_ctx* c, uint32_t w, uint32_t h, rt_hit* host_out) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!c->has_scene) return fail(c, RT_E_NO_SCENE, "no scene uploaded");
+    if (!c->has_camera) return fail(c, RT_E_NO_CAMERA, "no camera set");
+    if (!host_out || w == 0 || h == 0) return fail(c, RT_E_INVALID, "trace_primary: null output or empty image");
+    if ((uint64_t)w * h > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "trace_primary: w*h exceeds 2^32-1");
+    const int ns = (int)c->reps.size();
+    // contiguous row blocks, multiples of 8 rows so that 8x8 tiles stay whole
+    const uint32_t per = ((h + ns - 1) / ns + 7) / 8 * 8;
+    const int mode = c->mode();
+    return for_each_slot(c, [&](int s) -> int {
+        Replica& r = c->reps[s];
+        const uint32_t y0 = std::min<uint64_t>((uint64_t)per * s, h), y1 = std::min<uint64_t>((uint64_t)y0 + per, h);
+        if (y1 <= y0) return RT_OK;
+        const uint32_t rows = y1 - y0;
+        const size_t bytes = (size_t)rows * w * sizeof(rt_hit);
+        RT_HIP_SLOT(r, hipSetDevice(r.device));
+        if (bytes > r.out_cap) {
+            if (r.d_out) hipFree(r.d_out);
+            r.d_out = nullptr; r.out_cap = 0;
+            RT_HIP_SLOT(r, hipMalloc(&r.d_out, bytes));
+            r.out_cap = bytes;
+        }
+        RT_HIP_SLOT(r, launch_primary(c->dev_scene(r), c->cam, mode, false, w, h, y0, rows, rows, 1, 1, 0, 0, nullptr,
+                                      static_cast<rt_hit*>(r.d_out), r.d_counters, r.stream));
+        RT_HIP_SLOT(r, hipMemcpyAsync(host_out + (size_t)y0 * w, r.d_out, bytes, hipMemcpyDeviceToHost, r.stream));
+        RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        return RT_OK;
+    });
+}
+
+static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool any_hit) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!c->has_scene) return fail(c, RT_E_NO_SCENE, "no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!rays || !out) return fail(c, RT_E_INVALID, "trace: null host pointer");
+    const int ns = (int)c->reps.size();
+    const uint64_t per = (n + ns - 1) / ns;
+    const size_t osz = any_hit ? 1 : sizeof(rt_hit);
+    const int mode = c->mode();
+    return for_each_slot(c, [&](int s) -> int {
+        Replica& r = c->reps[s];
+        const uint64_t b = std::min(per * s, n), e = std::min(b + per, n);
+        if (e <= b) return RT_OK;
+        const uint64_t chunk = std::min<uint64_t>(kChunkRays, e - b);
+        RT_HIP_SLOT(r, hipSetDevice(r.device));
+        if (chunk * sizeof(rt_ray) > r.rays_cap) {
+            if (r.d_rays) hipFree(r.d_rays);
+            r.d_rays = nullptr; r.rays_cap = 0;
+            RT_HIP_SLOT(r, hipMalloc(&r.d_rays, chunk * sizeof(rt_ray)));
+            r.rays_cap = chunk * sizeof(rt_ray);
+        }
+        if (chunk * osz > r.out_cap) {
+            if (r.d_out) hipFree(r.d_out);
+            r.d_out = nullptr; r.out_cap = 0;
+            RT_HIP_SLOT(r, hipMalloc(&r.d_out, chunk * osz));
+            r.out_cap = chunk * osz;
+        }
+        for (uint64_t i = b; i < e; i += chunk) {
+            const uint64_t m = std::min(chunk, e - i);
+            RT_HIP_SLOT(r, hipMemcpyAsync(r.d_rays, rays + i, m * sizeof(rt_ray), hipMemcpyHostToDevice, r.stream));
+            RT_HIP_SLOT(r, launch_trace(c->dev_scene(r), mode, any_hit, false, static_cast<const rt_ray*>(r.d_rays), m,
+                                        any_hit ? nullptr : static_cast<rt_hit*>(r.d_out),
+                                        any_hit ? static_cast<uint8_t*>(r.d_out) : nullptr, r.d_counters, r.stream));
+            RT_HIP_SLOT(r, hipMemcpyAsync(static_cast<char*>(out) + i * osz, r.d_out, m * osz, hipMemcpyDeviceToHost, r.stream));
+            RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        }
+        return RT_OK;
+    });
+}
+
+int rt_trace(rt_ctx* c, const rt_ray* host_rays, uint64_t n, rt_hit* host_out) {
+    return trace_host(c, host_rays, n, host_out, false);
+}
+int rt_occluded(rt_ctx* c, const rt_ray* host_rays, uint64_t n, uint8_t* host_out) {
+    return trace_host(c, host_rays, n, host_out, true);
+}
+
+}  // extern "C"
