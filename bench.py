@@ -1,0 +1,222 @@
+"""bench.py -- closest-hit throughput of the HIP hot path on the BASELINE.json headline config.
+
+Workload (config.workload): C3 of BASELINE.md -- the "Sponza-class" scene the north_star target
+(>= 1 Gray/s closest-hit per MI355X) is quoted on.  The real Sponza mesh is not in the reference and
+cannot be fetched, so the scene is the labelled procedural stand-in of SURVEY.md 8(d): 8 x 8
+sphereGeometry(45,45) in a closed room = 259,212 triangles.  One step = one 3840x2160 frame at 4 spp:
+  1. jittered primary rays generated on device + closest hit   (k_primary, 33.2 M rays, coherent)
+  2. cosine-weighted bounce rays from the hits                  (k_bounce)
+  3. closest hit of the bounce rays                             (k_trace, 33.2 M rays, incoherent)
+  4. N > 1 only: all-gather of the per-rank hit slices over RCCL/xGMI and de-interleave
+Everything stays in HBM; value = closest-hit rays of the whole job / wall time (max over ranks).
+With N ranks the frame's 16-row stripes are interleaved over the ranks (strong scaling).
+
+Usage: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracer_amd as rt                      # noqa: E402
+from raytracer_amd import dist as rd            # noqa: E402
+from raytracer_amd import scenes                # noqa: E402
+
+W, H, SPP, SEED, STRIPE = 3840, 2160, 4, 1, 16
+PEAK_VALU_TFLOPS = 157.3      # MI355X fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0         # HBM3E spec peak (same table); 6.29 TB/s measured achievable
+CPU_SAMPLE = 65536            # rays per generation in the CPU-baseline / parity sample
+
+
+def flops_bytes_per_ray(c, generated):
+    """flops/ray = 24 B + 53 T + 45 G; bytes/ray = 64 N + 48 T + IO."""
+    rays = max(c["rays"], 1)
+    B, N, T = c["box_tests"] / rays, c["nodes"] / rays, c["tri_tests"] / rays
+    flops = 24.0 * B + 53.0 * T + (45.0 if generated else 0.0)
+    nbytes = 64.0 * N + 48.0 * T + (16.0 if generated else 48.0)
+    return flops, nbytes, {"B": round(B, 2), "N": round(N, 2), "T": round(T, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- scene setup: flatten + upload to this rank's HBM (BVH replicated per GPU) -------------------
+    tris, sph, lights, cam = scenes.sponza_class()
+    r = rt.Renderer((local_rank,))
+    r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    stats = r.create_data(tris, sph, lights)
+    r.update_camera(cam)
+
+    plan = rd.stripe_plan(H, world, rank, STRIPE)
+    n_local = plan.padded_rows * W * SPP                 # local ray slots (padding rows are dead rays)
+    rays_per_step = W * H * SPP * 2                      # whole job: primary + bounce
+    f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+    rays, brays = f32(n_local * 8), f32(n_local * 8)
+    hits = f32(n_local * 2 * 4)                          # [primary | bounce] hit records, gathered as one buffer
+    phits, bhits = hits[: n_local * 4], hits[n_local * 4:]
+    gidx = rd.gather_index(plan, dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def stage_primary():
+        r.trace_primary_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, world, phits, rays, spp=SPP, seed=SEED,
+                                    jitter=True, stream=stream)
+
+    def stage_bounce_gen():
+        r.bounce_dev(rays, phits, n_local, brays, key0=0, seed=SEED, stream=stream)
+
+    def stage_bounce_trace():
+        r.trace_dev(brays, n_local, bhits, stream=stream)
+
+    def stage_gather():
+        if world == 1:
+            return None
+        both = hits.view(2, plan.padded_rows, W * SPP * 4).transpose(0, 1).contiguous()   # rows first
+        return rd.gather_rows(both, plan, gidx)                                         # [H, 2, W*SPP*4]
+
+    def step():
+        stage_primary()
+        stage_bounce_gen()
+        stage_bounce_trace()
+        return stage_gather()
+
+    # ---- instrumented pass: B, N, T per ray (same kernels with counters on) --------------------------
+    r.set_option(rt.OPT_COUNTERS, 1)
+    r.counters()
+    stage_primary(); torch.cuda.synchronize()
+    c_primary = r.counters()
+    stage_bounce_gen(); stage_bounce_trace(); torch.cuda.synchronize()
+    c_bounce = r.counters()
+    r.set_option(rt.OPT_COUNTERS, 0)
+
+    # ---- warmup, then exactly K timed steps ------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        stage_primary()
+        ev[k][1].record(stream)
+        stage_bounce_gen()
+        ev[k][2].record(stream)
+        stage_bounce_trace()
+        ev[k][3].record(stream)
+        stage_gather()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_primary = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
+    ms_bgen = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+    ms_btrace = float(np.mean([ev[k][2].elapsed_time(ev[k][3]) for k in range(args.steps)]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = rays_per_step * args.steps / elapsed / 1e6
+    n_real_local = c_primary["rays"]                     # live rays this rank traces per generation
+    fl_p, by_p, w_p = flops_bytes_per_ray(c_primary, True)
+    fl_b, by_b, w_b = flops_bytes_per_ray(c_bounce, False)
+    live_b = c_bounce["rays"]
+    # dominant kernel = the incoherent bounce closest-hit launch (k_trace)
+    ach_tflops = fl_b * live_b / (ms_btrace * 1e-3) / 1e12
+    ach_gbs = by_b * live_b / (ms_btrace * 1e-3) / 1e9
+    pmc = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path)).get("k_trace_hbm_bytes_per_launch")
+        except Exception:
+            pmc = None
+    roofline = {"bound": "valu", "kernel": "k_trace<bvh2> (bounce closest-hit)", "achieved": round(ach_tflops, 3),
+                "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / PEAK_VALU_TFLOPS, 4),
+                "traffic": pmc, "flops_per_ray": round(fl_b, 1), "work_per_ray": w_b,
+                "launch_ms": round(ms_btrace, 4), "rays_per_launch": int(live_b)}
+    roofline_hbm = {"bound": "hbm", "kernel": roofline["kernel"], "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(ach_gbs / PEAK_HBM_GBS, 4), "traffic": pmc,
+                    "bytes_per_ray": round(by_b, 1),
+                    "note": "algorithmic bytes are an upper bound on HBM traffic: the 33 MB structure is L2/MALL resident"}
+
+    out = {
+        "metric": "closest-hit Mrays/s", "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3 sponza-class stand-in (8x8 sphereGeometry(45,45) in a room, 259212 tris), "
+                               "3840x2160 x 4 spp jittered primary + 1 cosine-weighted bounce, closest-hit",
+                   "rays_per_step": rays_per_step, "parallelism": f"stripes{STRIPE}x{world}",
+                   "bvh": {"nodes": stats["n_nodes"], "depth": stats["max_depth"], "node_bytes": stats["node_bytes"],
+                           "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
+        "roofline": roofline, "roofline_hbm": roofline_hbm,
+        "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_ms": round(ms_primary, 4),
+                    "primary_work_per_ray": w_p, "primary_tflops": round(fl_p * n_real_local / (ms_primary * 1e-3) / 1e12, 3),
+                    "bounce_gen_ms": round(ms_bgen, 4),
+                    "bounce_Mrays_s": round(live_b / ms_btrace / 1e3, 1), "bounce_ms": round(ms_btrace, 4)},
+    }
+
+    # ---- CPU baseline (oracle = reference semantics, brute force) + parity gate on the same sample --------
+    if not args.no_cpu_baseline:
+        import oracle
+        torch.cuda.synchronize()
+        live = plan.local_stripes * STRIPE * W * SPP if world > 1 else W * H * SPP
+        live = min(live, n_local)
+        idx = np.sort(np.random.default_rng(0).choice(live, CPU_SAMPLE, replace=False))
+        tidx = torch.from_numpy(idx).to(dev)
+        take = lambda buf, k: buf.view(-1, k).index_select(0, tidx).cpu().numpy()
+        s_rays = take(rays, 8).view(rt.RAY).ravel()
+        s_brays = take(brays, 8).view(rt.RAY).ravel()
+        s_hits = take(phits, 4).view(rt.HIT).ravel()
+        s_bhits = take(bhits, 4).view(rt.HIT).ravel()
+        sc = oracle.Scene(tris, sph)
+        tc = time.perf_counter()
+        o_hits = oracle.trace(sc, s_rays)
+        o_bhits = oracle.trace(sc, s_brays)
+        cpu_s = time.perf_counter() - tc
+        mism = int((o_hits["prim"] != s_hits["prim"]).sum() + (o_bhits["prim"] != s_bhits["prim"]).sum())
+        exact = (o_hits.tobytes() == s_hits.tobytes()) and (o_bhits.tobytes() == s_bhits.tobytes())
+        out["cpu_baseline"] = {"value": round(2 * CPU_SAMPLE / cpu_s / 1e6, 4), "unit": "Mrays/s",
+                               "cores": oracle.num_threads(), "kind": "port",
+                               "sample": f"{CPU_SAMPLE} primary + {CPU_SAMPLE} bounce rays of the same frame (seeded "
+                                         f"subset), brute force over all 259212 triangles, {cpu_s:.1f} s"}
+        out["parity"] = {"sample_rays": 2 * CPU_SAMPLE, "prim_id_mismatches": mism, "hit_records_bit_exact": bool(exact)}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

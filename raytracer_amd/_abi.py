@@ -68,6 +68,14 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built. "
             "Run `make -C raytracer_amd/csrc` (hipcc cross-compiles gfx950 without a GPU). "
             "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    # libamdhip64.so.7, the one this library needs too) but link it as "libamdhip64.so".  If this library were
+    # loaded first it would pull /opt/rocm's copy, torch would then load a second runtime, and whichever
+    # initialises second cannot open the GPU.  Loading torch first makes the dynamic linker reuse its copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing

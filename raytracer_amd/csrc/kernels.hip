@@ -271,6 +271,12 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
             rays_out[2 * r + 1] = make_float4(d.x, d.y, d.z, tmax);
         }
         hits[r] = pack_hit(b, tmax);
+    } else if (wave < n_waves && x < w && yl < rows) {
+        // padding row of an interleaved share (image row >= h): a miss record and a dead ray, so that
+        // later stages that sweep the whole local buffer see well-defined input
+        const size_t r = ((size_t)yl * w + x) * spp + smp;
+        if (rays_out) { rays_out[2 * r] = make_float4(0, 0, 0, 0); rays_out[2 * r + 1] = make_float4(0, 0, 0, 0); }
+        hits[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS));
     }
     flush_counters<COUNT>(c, active, counters);
 }

@@ -1,0 +1,105 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, scene replicated, work split, one gather.
+
+The reference is single-device (one VkDevice, src/vulkan/VkRenderer.cpp:1576-1609); everything here is
+build-original.  Rays and pixels are independent (shaders/frag.glsl:303-360 has no
+cross-pixel communication), so the only exchange is the gather of per-rank result slices:
+
+  * image configs: the frame is cut into horizontal stripes of `stripe_h` rows (a multiple of the 8x8
+    wave tile); rank r owns stripes r, r+N, r+2N, ... (interleaved, because cost is spatially uneven);
+    the per-rank buffers are all-gathered (RCCL over xGMI when the backend is "nccl") and
+    de-interleaved into image order on every rank.
+  * ray-buffer configs (C4): contiguous ranges of ceil(n/N) rays per rank, all-gathered the same way.
+
+No reduction is involved, so no all-reduce: each element has exactly one owner.
+torch.distributed is plumbing here (process group + collective); the math is index bookkeeping.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class StripePlan:
+    h: int            # image rows
+    world: int
+    rank: int
+    stripe_h: int     # rows per stripe
+    n_stripes: int    # stripes in the whole image (last one may be short)
+    max_local: int    # stripes owned by rank 0 (= the padded per-rank count)
+
+    @property
+    def y0(self):
+        return self.rank * self.stripe_h
+
+    @property
+    def local_stripes(self):
+        return len(range(self.rank, self.n_stripes, self.world))
+
+    @property
+    def padded_rows(self):
+        """Rows of the per-rank buffer: identical on every rank so that all_gather needs no sizes."""
+        return self.max_local * self.stripe_h
+
+    def local_to_global_rows(self, rank=None):
+        """Image row of every local row of `rank` (rows past the image bottom map to -1)."""
+        rank = self.rank if rank is None else rank
+        rows = []
+        for k in range(self.max_local):
+            s = rank + k * self.world
+            for yy in range(self.stripe_h):
+                y = s * self.stripe_h + yy
+                rows.append(y if (s < self.n_stripes and y < self.h) else -1)
+        return rows
+
+
+def stripe_plan(h, world, rank, stripe_h=16):
+    if stripe_h <= 0 or stripe_h % 8:
+        raise ValueError("stripe_h must be a positive multiple of 8 (the wave tile height)")
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    n_stripes = (h + stripe_h - 1) // stripe_h
+    max_local = (n_stripes + world - 1) // world
+    return StripePlan(h, world, rank, stripe_h, n_stripes, max_local)
+
+
+def gather_index(plan, device):
+    """For the concatenation [rank0 rows | rank1 rows | ...] of padded per-rank buffers: the position
+    of every image row, as an int64 tensor of length h (used with index_select)."""
+    pos = [0] * plan.h
+    for r in range(plan.world):
+        for local, y in enumerate(plan.local_to_global_rows(r)):
+            if y >= 0:
+                pos[y] = r * plan.padded_rows + local
+    return torch.tensor(pos, dtype=torch.int64, device=device)
+
+
+def gather_rows(local, plan, index=None, group=None):
+    """local: [padded_rows, row_elems...] tensor of this rank -> [h, row_elems...] on every rank."""
+    if local.shape[0] != plan.padded_rows:
+        raise ValueError(f"local buffer has {local.shape[0]} rows, plan needs {plan.padded_rows}")
+    if plan.world == 1:
+        full = local
+    else:
+        full = torch.empty((plan.world * plan.padded_rows,) + tuple(local.shape[1:]), dtype=local.dtype,
+                           device=local.device)
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    if index is None:
+        index = gather_index(plan, local.device)
+    return full.index_select(0, index)
+
+
+def shard_range(n, world, rank):
+    """Contiguous range [first, first+count) of rank; every rank's padded count is ceil(n/world)."""
+    per = (n + world - 1) // world
+    first = min(rank * per, n)
+    return first, min(per, n - first), per
+
+
+def gather_ranges(local, n, world, group=None):
+    """local: [per, ...] (padded) -> [n, ...] in ray order on every rank."""
+    if world == 1:
+        return local[:n]
+    full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    return full[:n]

@@ -25,6 +25,12 @@ def material12(albedo=(1, 1, 1), emission=(0, 0, 0), strength=0.0, roughness=0.0
     return m
 
 
+def cat(parts):
+    """Concatenate TRIANGLE arrays bytewise (np.concatenate would repack the padded struct dtype)."""
+    raw = np.concatenate([np.ascontiguousarray(p).view(np.uint8).reshape(-1, TRIANGLE.itemsize) for p in parts])
+    return raw.reshape(-1).view(TRIANGLE)
+
+
 def cornell():
     """C1: 12 triangles + 3 spheres, 0 lights (src/vulkan/VkRenderer.cpp:171-258)."""
     L = lib()
@@ -53,7 +59,7 @@ def cornell32():
     tris, sph, lights = cornell()
     gold = np.frombuffer(sph[0:1].tobytes(), dtype=np.float32)[4:16]
     geo = sphere_geometry(sph[0]["center"], float(sph[0]["radius"]), 2, 5, gold)
-    return np.concatenate([tris, geo]), sph[1:].copy(), lights
+    return cat([tris, geo]), sph[1:].copy(), lights
 
 
 def _quad(p0, p1, p2, p3, normal, mat):
@@ -81,7 +87,7 @@ def box(lo, hi, mat=None):
         _quad((x0, y0, z0), (x0, y1, z0), (x0, y1, z1), (x0, y0, z1), (1, 0, 0), mat),    # x = x0 wall
         _quad((x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0), (-1, 0, 0), mat),   # x = x1 wall
     ]
-    return np.concatenate(q)
+    return cat(q)
 
 
 def bunny_class():
@@ -89,7 +95,7 @@ def bunny_class():
     quad (so that the shadow ray has something to fall on); one point light.  NOT the Stanford Bunny."""
     body = sphere_geometry((0.0, 0.0, 1.0), 1.0, 186, 186, material12((0.8, 0.8, 0.7)))
     ground = _quad((-6, -6, 0), (6, -6, 0), (6, 6, 0), (-6, 6, 0), (0, 0, 1), material12())
-    tris = np.concatenate([body, ground])
+    tris = cat([body, ground])
     lights = np.zeros(1, dtype=LIGHT)
     lights[0]["position"] = (3.0, 3.0, 5.0)
     lights[0]["color"] = (1, 1, 1)
@@ -107,7 +113,7 @@ def sponza_class():
             z = 0.8 + 0.35 * ((i * 3 + j * 5) % 7)
             alb = (0.3 + 0.1 * (i % 5), 0.3 + 0.1 * (j % 5), 0.6)
             parts.append(sphere_geometry((-7.0 + 2.0 * i, -7.0 + 2.0 * j, z), 0.8, 45, 45, material12(alb)))
-    tris = np.concatenate(parts)
+    tris = cat(parts)
     cam = camera_look_at((0.3, 8.0, 2.6), (0.0, 0.0, 1.2), 60.0, 3840.0 / 2160.0)
     return tris, np.zeros(0, dtype=SPHERE), np.zeros(0, dtype=LIGHT), cam
 

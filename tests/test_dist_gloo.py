@@ -1,0 +1,84 @@
+"""CPU tests of the multi-GPU sharding logic (raytracer_amd/dist.py) with world_size-2 gloo groups."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd import dist as rd
+
+
+def test_stripe_plan_covers_every_row_once():
+    for h, world, sh in ((2160, 8, 16), (1080, 4, 8), (37, 2, 8), (5, 3, 8), (64, 1, 16)):
+        seen = np.zeros(h, dtype=int)
+        for r in range(world):
+            p = rd.stripe_plan(h, world, r, sh)
+            rows = p.local_to_global_rows()
+            assert len(rows) == p.padded_rows
+            for y in rows:
+                if y >= 0:
+                    seen[y] += 1
+        assert (seen == 1).all(), (h, world, sh)
+        idx = rd.gather_index(rd.stripe_plan(h, world, 0, sh), "cpu")
+        assert len(set(idx.tolist())) == h
+
+
+def test_kernel_row_formula_matches_plan():
+    """k_primary maps local row yl to y0 + (yl // sh) * sh * step + yl % sh (kernels.hip)."""
+    for h, world, sh in ((2160, 8, 16), (37, 2, 8)):
+        for r in range(world):
+            p = rd.stripe_plan(h, world, r, sh)
+            for yl, y in enumerate(p.local_to_global_rows()):
+                yk = p.y0 + (yl // sh) * sh * world + yl % sh
+                assert (y == yk) if y >= 0 else (yk >= h)
+
+
+def test_shard_range():
+    n, world = 1003, 4
+    got = []
+    for r in range(world):
+        first, cnt, per = rd.shard_range(n, world, r)
+        assert per == 251
+        got += list(range(first, first + cnt))
+    assert got == list(range(n))
+    assert rd.shard_range(2, 4, 3) == (2, 0, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, h, w, sh, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # image: every rank fills its own stripes with f(global pixel), garbage elsewhere
+        p = rd.stripe_plan(h, world, rank, sh)
+        local = torch.full((p.padded_rows, w, 4), -7.0)
+        for yl, y in enumerate(p.local_to_global_rows()):
+            if y >= 0:
+                local[yl] = (torch.arange(w, dtype=torch.float32)[:, None] + y * w) * torch.tensor([1.0, 2.0, 3.0, 4.0])
+        full = rd.gather_rows(local, p)
+        want = (torch.arange(h * w, dtype=torch.float32).reshape(h, w, 1)) * torch.tensor([1.0, 2.0, 3.0, 4.0])
+        assert torch.equal(full, want)
+        # ray ranges
+        first, cnt, per = rd.shard_range(n, world, rank)
+        loc = torch.zeros(per, 4)
+        loc[:cnt, 0] = torch.arange(first, first + cnt, dtype=torch.float32)
+        allr = rd.gather_ranges(loc, n, world)
+        assert torch.equal(allr[:, 0], torch.arange(n, dtype=torch.float32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w,sh,n", [(37, 5, 8, 101), (64, 8, 16, 64)])
+def test_gather_world2_gloo(h, w, sh, n):
+    mp.spawn(_worker, args=(2, _free_port(), h, w, sh, n), nprocs=2, join=True)

@@ -1,0 +1,378 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the golden fixtures.
+
+Bar (BASELINE.json north_star): primitive IDs bit-exact, t/u/v within 1e-5 relative.  Because the kernels
+and the oracle fix the same fp32 evaluation order (DESIGN.md "Arithmetic contract"), these tests ask for
+MORE: the whole 16-byte hit record must be bit-identical; `assert_parity` reports the prim-ID mismatch
+rate and the worst relative error when it is not.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import raytracer_amd as rt
+from raytracer_amd import dist as rd
+from raytracer_amd import scenes
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5      # north_star tolerance for t, u, v (we require bit-exactness, this is only reported)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def assert_parity(got, ref, what):
+    got, ref = got.ravel(), ref.ravel()
+    assert got.shape == ref.shape, what
+    if got.tobytes() == ref.tobytes():
+        return
+    bad = got["prim"] != ref["prim"]
+    rel = 0.0
+    for f in ("t", "u", "v"):
+        a, b = got[f][~bad].astype(np.float64), ref[f][~bad].astype(np.float64)
+        rel = max(rel, float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30), initial=0.0)))
+    first = np.flatnonzero(got.view(np.uint32).reshape(-1, 4) != ref.view(np.uint32).reshape(-1, 4))[:1]
+    raise AssertionError(f"{what}: prim-ID mismatches {int(bad.sum())}/{got.size} "
+                         f"({bad.mean():.3e}), max rel err t/u/v {rel:.3e} (tol {REL_TOL}); first diff at word {first}")
+
+
+def mk_rays(o, d, tmin=0.0, tmax=1e20):
+    o, d = np.atleast_2d(np.asarray(o, dtype=np.float32)), np.atleast_2d(np.asarray(d, dtype=np.float32))
+    r = np.zeros(len(o), dtype=rt.RAY)
+    r["o"], r["d"], r["tmin"], r["tmax"] = o, d, tmin, tmax
+    return r
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture()
+def renderer():
+    r = rt.Renderer((0,))
+    yield r
+    r.close()
+
+
+def dev_buf(torch, n_items, itemsize):
+    return torch.empty(n_items * itemsize // 4, dtype=torch.float32, device="cuda")
+
+
+def to_np(t, dtype):
+    return t.cpu().numpy().view(dtype)
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.float32).reshape(-1).copy()).cuda()
+
+
+# ---- C1: Cornell box, the reference's own scene ------------------------------------------------------
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_AUTO, rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+def test_c1_cornell_512_full_frame_bit_exact(renderer, mode):
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(1.0)
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    renderer.create_data(tris, sph)
+    renderer.update_camera(cam)
+    got = renderer.trace_primary(512, 512)
+    assert_parity(got, oracle.trace_primary(oracle.Scene(tris, sph), cam, 512, 512), f"C1 512x512 mode {mode}")
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    assert sha(got) == meta["c1_cornell_512x512_sha256"]
+    assert (got["prim"] != rt.MISS).all()                      # closed box: every primary ray hits
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+def test_kats_on_gpu(renderer, mode):
+    tris, sph, _ = scenes.cornell()
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    renderer.create_data(tris, sph)
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    for name, k in kat.items():
+        h = renderer.trace(mk_rays(k["o"], k["d"]))[0]
+        assert int(h["prim"]) == k["prim"], f"{name}: a BVH that returns the other triangle of the tie fails here"
+        assert (float(h["t"]), float(h["u"]), float(h["v"])) == (k["t"], k["u"], k["v"]), name
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+def test_golden_fixtures_on_gpu(renderer, mode):
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    tris, sph, _ = scenes.cornell()
+    renderer.create_data(tris, sph)
+    renderer.update_camera(rt.default_camera(1.0))
+    assert_parity(renderer.trace_primary(64, 64), np.load(os.path.join(GOLDEN, "c1_cornell_64x64_hits.npy")), "golden 64x64")
+    renderer.update_camera(rt.default_camera())
+    assert_parity(renderer.trace_primary(61, 37), np.load(os.path.join(GOLDEN, "c1_cornell_61x37_hits.npy")), "golden ragged 61x37")
+    t32, s32, _ = scenes.cornell32()
+    renderer.create_data(t32, s32)
+    renderer.update_camera(rt.default_camera(1.0))
+    assert_parity(renderer.trace_primary(64, 64), np.load(os.path.join(GOLDEN, "c1_32_cornell_64x64_hits.npy")), "golden C1-32")
+    st, rays = scenes.soup(2000, half_extent=0.05), scenes.random_rays(4096)
+    renderer.create_data(st)
+    assert_parity(renderer.trace(rays), np.load(os.path.join(GOLDEN, "soup2k_rays4k_hits.npy")), "golden soup")
+
+
+def test_shadow_and_bounce_stages_vs_golden(renderer, torch_dev):
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(1.0)
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(tris, sph)
+    renderer.update_camera(cam)
+    n = 64 * 64
+    rays, hits = dev_buf(torch, n, 32), dev_buf(torch, n, 16)
+    srays, brays = dev_buf(torch, n, 32), dev_buf(torch, n, 32)
+    lit = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream()
+    renderer.trace_primary_dev(64, 64, hits, rays, stream=s)
+    renderer.shadow_dev(rays, hits, n, (0.0, 0.0, 1.9), lit, srays, stream=s)
+    renderer.bounce_dev(rays, hits, n, brays, key0=0, seed=7, stream=s)
+    torch.cuda.synchronize()
+    sc = oracle.Scene(tris, sph)
+    assert to_np(rays, rt.RAY).tobytes() == oracle.primary_rays(cam, 64, 64).tobytes()
+    assert_parity(to_np(hits, rt.HIT), np.load(os.path.join(GOLDEN, "c1_cornell_64x64_hits.npy")), "primary_dev")
+    assert lit.cpu().numpy().tobytes() == np.load(os.path.join(GOLDEN, "c1_cornell_64x64_lit.npy")).tobytes()
+    _, sr = oracle.shadow_lit(sc, to_np(rays, rt.RAY), to_np(hits, rt.HIT), (0.0, 0.0, 1.9), want_rays=True)
+    assert to_np(srays, rt.RAY).tobytes() == sr.tobytes()
+    assert to_np(brays, rt.RAY).tobytes() == np.load(os.path.join(GOLDEN, "c1_cornell_64x64_bounce_rays.npy")).tobytes()
+    assert 0 < int((lit == 0).sum()) < n                        # the spheres do cast shadows
+
+
+def test_jittered_spp_primary_rays_bit_exact(renderer, torch_dev):
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(1.0)
+    renderer.create_data(tris, sph)
+    renderer.update_camera(cam)
+    w, h, spp = 32, 32, 4
+    rays, hits = dev_buf(torch, w * h * spp, 32), dev_buf(torch, w * h * spp, 16)
+    renderer.trace_primary_dev(w, h, hits, rays, spp=spp, seed=1, jitter=True, stream=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    ref_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=1, jitter=True)
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    assert to_np(rays, rt.RAY).tobytes() == ref_rays.tobytes()
+    assert sha(to_np(rays, rt.RAY)) == meta["c1_cornell_rays_32x32x4_seed1_sha256"]
+    assert_parity(to_np(hits, rt.HIT), oracle.trace(oracle.Scene(tris, sph), ref_rays), "jittered primary hits")
+
+
+# ---- edge cases -----------------------------------------------------------------------------------------
+def test_empty_scene_and_empty_ray_buffer(renderer):
+    renderer.create_data()
+    h = renderer.trace(mk_rays([(0, 0, 0), (1, 2, 3)], [(0, 0, 1), (1, 0, 0)]))
+    assert (h["prim"] == rt.MISS).all() and (h["t"] == np.float32(1e20)).all() and (h["u"] == 0).all()
+    assert renderer.trace(np.zeros(0, dtype=rt.RAY)).size == 0
+    assert renderer.occluded(np.zeros(0, dtype=rt.RAY)).size == 0
+    renderer.update_camera(rt.default_camera())
+    assert (renderer.trace_primary(9, 5)["prim"] == rt.MISS).all()
+
+
+def test_spheres_only_and_sphere_tie_rule(renderer):
+    sph = np.zeros(2, dtype=rt.SPHERE)
+    sph[0]["center"], sph[0]["radius"] = (0, 0, 0), 1.0
+    sph[1]["center"], sph[1]["radius"] = (0, 0, 0), 1.0          # identical twin: the lower index wins the tie
+    tri = np.zeros(1, dtype=rt.TRIANGLE)
+    tri[0]["v0"]["position"], tri[0]["v1"]["position"], tri[0]["v2"]["position"] = (-4, -4, 1), (4, -4, 1), (0, 8, 1)
+    rays = mk_rays([(0, 0, 3), (0, 0, 0), (5, 5, 5)], [(0, 0, -1), (0, 0, 1), (0, 0, 1)])
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH):
+        renderer.set_option(rt.OPT_TRAVERSAL, mode)
+        renderer.create_data(None, sph)
+        assert_parity(renderer.trace(rays), oracle.trace(oracle.Scene(None, sph), rays), "spheres only")
+        renderer.create_data(tri, sph)
+        got = renderer.trace(rays)
+        assert_parity(got, oracle.trace(oracle.Scene(tri, sph), rays), "sphere vs triangle tie")
+        assert int(got[0]["prim"]) == rt.SPHERE_BIT and float(got[0]["t"]) == 2.0
+
+
+def test_intervals_degenerates_and_axis_aligned_rays(renderer):
+    tris, sph, _ = scenes.cornell()
+    z = np.zeros(3, dtype=rt.TRIANGLE)                            # zero triangles (VkRenderer.cpp:262-270 placeholder)
+    tris = scenes.cat([tris, z])
+    sc = oracle.Scene(tris, sph)
+    o = [(0, 4, 1), (0, 4, 1), (0, 4, 1), (0.5, 1, 1), (0, 0, 1), (2, 0, 1), (-2, -2, 0), (0, 0, 1), (0, 0, 1), (100, 100, 100)]
+    d = [(0, -1, 0), (0, -1, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (1, 0, 0), (1, 1, 1), (1, 0, 0), (0, 0, 1), (-1, -1, -1)]
+    rays = mk_rays(o, d)
+    rays["tmax"][1] = 6.0           # hit exactly at tmax is rejected
+    rays["tmin"][2] = 6.5           # interval beyond the hit
+    rays["tmax"][3] = 0.0           # empty interval
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH):
+        renderer.set_option(rt.OPT_TRAVERSAL, mode)
+        renderer.create_data(tris, sph)
+        assert_parity(renderer.trace(rays), oracle.trace(sc, rays), f"edge rays mode {mode}")
+        assert np.array_equal(renderer.occluded(rays), oracle.occluded(sc, rays))
+
+
+def test_error_conventions(renderer):
+    with pytest.raises(RuntimeError, match="no scene"):
+        renderer.trace(mk_rays((0, 0, 0), (0, 0, 1)))
+    renderer.create_data(*scenes.cornell()[:2])
+    with pytest.raises(RuntimeError, match="no camera"):
+        renderer.trace_primary(8, 8)
+    with pytest.raises(RuntimeError):
+        renderer.set_option(99, 0)
+    bad = np.zeros(4, dtype=rt.TRIANGLE)
+    bad[1]["v0"]["position"] = (np.nan, 0, 0)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        renderer.create_data(bad)
+    with pytest.raises(RuntimeError):
+        rt.Renderer((99,))
+
+
+# ---- random soups: BVH vs the reference loop ---------------------------------------------------------------
+@pytest.mark.parametrize("n_tris,half,n_rays,leaf", [(1, 0.3, 2000, 4), (5, 0.3, 2000, 4), (20000, 0.02, 60000, 4),
+                                                     (20000, 0.02, 30000, 1), (3000, 0.2, 30000, 8)])
+def test_soup_bvh_and_brute_vs_oracle(renderer, n_tris, half, n_rays, leaf):
+    st, rays = scenes.soup(n_tris, half_extent=half), scenes.random_rays(n_rays)
+    rays["o"][: n_rays // 4] = rays["o"][: n_rays // 4] * 4 - 2          # a quarter start outside the unit cube
+    ref = oracle.trace(oracle.Scene(st), rays)
+    assert (ref["prim"] != rt.MISS).any()
+    renderer.set_option(rt.OPT_MAX_LEAF, leaf)
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH):
+        renderer.set_option(rt.OPT_TRAVERSAL, mode)
+        stats = renderer.create_data(st)
+        assert stats["max_depth"] <= 31
+        assert_parity(renderer.trace(rays), ref, f"soup {n_tris} mode {mode} leaf {leaf}")
+        assert np.array_equal(renderer.occluded(rays), (ref["prim"] != rt.MISS).astype(np.uint8))
+
+
+def test_two_slots_on_one_device_equal_one_slot():
+    st, rays = scenes.soup(5000, half_extent=0.05), scenes.random_rays(10001)
+    tris, sph, _ = scenes.cornell()
+    with rt.Renderer((0,)) as a, rt.Renderer((0, 0, 0)) as b:
+        assert b.num_slots == 3
+        for r in (a, b):
+            r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+            r.create_data(st)
+        assert a.trace(rays).tobytes() == b.trace(rays).tobytes()
+        assert a.occluded(rays).tobytes() == b.occluded(rays).tobytes()
+        for r in (a, b):
+            r.create_data(tris, sph)
+            r.update_camera(rt.default_camera())
+        assert a.trace_primary(61, 37).tobytes() == b.trace_primary(61, 37).tobytes()
+
+
+# ---- C2 / C3 stand-ins: sampled against the oracle, full frames against the GPU brute-force loop --------------
+def test_c2_bunny_class_primary_and_shadow_sample(renderer, torch_dev):
+    torch = torch_dev
+    tris, sph, lights, cam = scenes.bunny_class()
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(tris, sph, lights)
+    renderer.update_camera(cam)
+    w, h = 1920, 1080
+    n = w * h
+    rays, hits = dev_buf(torch, n, 32), dev_buf(torch, n, 16)
+    lit = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream()
+    renderer.trace_primary_dev(w, h, hits, rays, stream=s)
+    renderer.shadow_dev(rays, hits, n, tuple(lights[0]["position"]), lit, stream=s)
+    torch.cuda.synchronize()
+    hr, hh, hl = to_np(rays, rt.RAY), to_np(hits, rt.HIT), lit.cpu().numpy()
+    idx = np.random.default_rng(2).choice(n, 12000, replace=False)
+    sc = oracle.Scene(tris, sph)
+    assert hr[idx].tobytes() == oracle.primary_rays(cam, w, h)[idx].tobytes()
+    assert_parity(hh[idx], oracle.trace(sc, hr[idx]), "C2 primary sample")
+    assert np.array_equal(hl[idx], oracle.shadow_lit(sc, hr[idx], hh[idx], tuple(lights[0]["position"])))
+    assert set(np.unique(hl)) == {0, 1, 2}                     # lit, shadowed and sky pixels all occur
+
+
+def test_c3_sponza_class_primary_bounce_sample(renderer, torch_dev):
+    torch = torch_dev
+    tris, sph, _, cam = scenes.sponza_class()
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(tris, sph)
+    renderer.update_camera(cam)
+    w, h, spp = 960, 540, 4
+    n = w * h * spp
+    rays, hits, brays, bhits = dev_buf(torch, n, 32), dev_buf(torch, n, 16), dev_buf(torch, n, 32), dev_buf(torch, n, 16)
+    s = torch.cuda.current_stream()
+    renderer.trace_primary_dev(w, h, hits, rays, spp=spp, seed=1, jitter=True, stream=s)
+    renderer.bounce_dev(rays, hits, n, brays, key0=0, seed=1, stream=s)
+    renderer.trace_dev(brays, n, bhits, stream=s)
+    torch.cuda.synchronize()
+    hr, hh, br, bh = to_np(rays, rt.RAY), to_np(hits, rt.HIT), to_np(brays, rt.RAY), to_np(bhits, rt.HIT)
+    sc = oracle.Scene(tris, sph)
+    idx = np.sort(np.random.default_rng(3).choice(n, 6000, replace=False))
+    assert_parity(hh[idx], oracle.trace(sc, hr[idx]), "C3 primary sample")
+    assert_parity(bh[idx], oracle.trace(sc, br[idx]), "C3 bounce sample")
+    # bounce generation: the oracle keys its RNG on the buffer index, so compare a contiguous head
+    head = 5000
+    assert br[:head].tobytes() == oracle.bounce(sc, hr[:head], hh[:head], seed=1).tobytes()
+    assert (hh["prim"] != rt.MISS).all() and (bh["prim"] != rt.MISS).mean() > 0.99     # closed room
+
+
+def test_full_frame_bvh_equals_reference_loop_on_gpu(renderer, torch_dev):
+    """Size-independent property at a size the CPU oracle cannot reach: the BVH kernel must return exactly
+    what the reference's brute-force loop (frag.glsl:282-298) returns, here run as the brute-force HIP
+    kernel (itself pinned bit-exactly to the oracle by the tests above).  1.0 M rays x 259 k triangles."""
+    torch = torch_dev
+    tris, sph, _, cam = scenes.sponza_class()
+    renderer.update_camera(cam)
+    w, h = 1280, 720
+    n = w * h
+    out = {}
+    for mode in (rt.TRAVERSAL_BVH, rt.TRAVERSAL_BRUTE):
+        renderer.set_option(rt.OPT_TRAVERSAL, mode)
+        renderer.create_data(tris, sph)
+        rays, hits, brays, bhits = dev_buf(torch, n, 32), dev_buf(torch, n, 16), dev_buf(torch, n, 32), dev_buf(torch, n, 16)
+        s = torch.cuda.current_stream()
+        renderer.trace_primary_dev(w, h, hits, rays, seed=5, jitter=True, stream=s)
+        renderer.bounce_dev(rays, hits, n, brays, seed=5, stream=s)
+        renderer.trace_dev(brays, n, bhits, stream=s)
+        torch.cuda.synchronize()
+        out[mode] = (to_np(hits, rt.HIT).copy(), to_np(bhits, rt.HIT).copy())
+    assert_parity(out[rt.TRAVERSAL_BVH][0], out[rt.TRAVERSAL_BRUTE][0], "full-frame primary: BVH vs reference loop")
+    assert_parity(out[rt.TRAVERSAL_BVH][1], out[rt.TRAVERSAL_BRUTE][1], "full-frame bounce: BVH vs reference loop")
+
+
+def test_counters_and_idempotence(renderer, torch_dev):
+    torch = torch_dev
+    st = scenes.soup(20000, half_extent=0.02)
+    rays = scenes.random_rays(50000)
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(st)
+    d_rays, d_hits = to_dev(torch, rays), dev_buf(torch, len(rays), 16)
+    s = torch.cuda.current_stream()
+    renderer.trace_dev(d_rays, len(rays), d_hits, stream=s)
+    torch.cuda.synchronize()
+    first = to_np(d_hits, rt.HIT).copy()
+    renderer.set_option(rt.OPT_COUNTERS, 1)
+    renderer.counters()
+    renderer.trace_dev(d_rays, len(rays), d_hits, stream=s)
+    torch.cuda.synchronize()
+    c = renderer.counters()
+    assert to_np(d_hits, rt.HIT).tobytes() == first.tobytes()            # instrumented kernel, same answers
+    assert c["rays"] == len(rays) and c["box_tests"] == 2 * c["nodes"] and c["tri_tests"] > 0
+    assert c["nodes"] / c["rays"] < 200
+
+
+# ---- multi-GPU sharding, both ranks emulated on the one GPU of this box ------------------------------------------
+def test_stripe_sharding_reassembles_the_full_frame(renderer, torch_dev):
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera()
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(tris, sph)
+    renderer.update_camera(cam)
+    w, h, spp = 200, 150, 2
+    s = torch.cuda.current_stream()
+    full = dev_buf(torch, w * h * spp, 16)
+    renderer.trace_primary_dev(w, h, full, spp=spp, seed=3, jitter=True, stream=s)
+    for world, sh in ((2, 16), (3, 8)):
+        parts = []
+        for rank in range(world):
+            p = rd.stripe_plan(h, world, rank, sh)
+            loc = torch.zeros(p.padded_rows * w * spp * 4, dtype=torch.float32, device="cuda")
+            renderer.trace_primary_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, loc, spp=spp, seed=3, jitter=True, stream=s)
+            parts.append(loc.view(p.padded_rows, w * spp * 4))
+        cat = torch.cat(parts, 0)
+        img = cat.index_select(0, rd.gather_index(rd.stripe_plan(h, world, 0, sh), "cuda"))
+        torch.cuda.synchronize()
+        assert to_np(img.reshape(-1), rt.HIT).tobytes() == to_np(full, rt.HIT).tobytes(), (world, sh)
