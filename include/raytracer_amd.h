@@ -12,7 +12,7 @@
  *     the reference's own convention (src/main.cpp:8-14).
  *   - one caller thread per rt_ctx.  host_* buffers stay owned by the caller.
  *   - *_dev entry points take DEVICE pointers valid on the context's device `slot` and enqueue on the
- *     given hipStream_t (NULL = the slot's own stream); they do not synchronise.
+ *     given hipStream_t, passed as void* (NULL = HIP's default stream); they do not synchronise.
  *   - all arithmetic is fp32; hit records are bit-exact against oracle/ (see DESIGN.md).
  */
 #ifndef RAYTRACER_AMD_H

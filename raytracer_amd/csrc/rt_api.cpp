@@ -89,11 +89,11 @@ int fail_hip(rt_ctx* c, hipError_t e, const char* what) {
     } while (0)
 
 void free_scene(Replica& r) {
-    hipSetDevice(r.device);
-    if (r.d_nodes) hipFree(r.d_nodes);
-    if (r.d_tris) hipFree(r.d_tris);
-    if (r.d_normals) hipFree(r.d_normals);
-    if (r.d_spheres) hipFree(r.d_spheres);
+    (void)hipSetDevice(r.device);
+    if (r.d_nodes) (void)hipFree(r.d_nodes);
+    if (r.d_tris) (void)hipFree(r.d_tris);
+    if (r.d_normals) (void)hipFree(r.d_normals);
+    if (r.d_spheres) (void)hipFree(r.d_spheres);
     r.d_nodes = r.d_tris = r.d_normals = r.d_spheres = nullptr;
 }
 
@@ -160,13 +160,13 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
     for (Replica& r : c->reps) {
-        hipSetDevice(r.device);
-        if (r.stream) hipStreamSynchronize(r.stream);
+        (void)hipSetDevice(r.device);
+        if (r.stream) (void)hipStreamSynchronize(r.stream);
         free_scene(r);
-        if (r.d_counters) hipFree(r.d_counters);
-        if (r.d_rays) hipFree(r.d_rays);
-        if (r.d_out) hipFree(r.d_out);
-        if (r.stream) hipStreamDestroy(r.stream);
+        if (r.d_counters) (void)hipFree(r.d_counters);
+        if (r.d_rays) (void)hipFree(r.d_rays);
+        if (r.d_out) (void)hipFree(r.d_out);
+        if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     delete c;
 }
@@ -333,7 +333,7 @@ int rt_trace_primary_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, ui
     if ((uint64_t)w * h * spp > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "primary: w*h*spp exceeds 2^32-1 (RNG key width)");
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
-    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), c->counters != 0, w, h, y0, rows, stripe_h, stripe_step,
                              spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st));
     return RT_OK;
@@ -351,7 +351,7 @@ int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* 
     if (n && (!d_rays || !d_hits)) return fail(c, RT_E_INVALID, "trace: null device pointer");
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
-    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), false, c->counters != 0, d_rays, n, d_hits, nullptr, r.d_counters, st));
     return RT_OK;
 }
@@ -362,7 +362,7 @@ int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8
     if (n && (!d_rays || !d_out)) return fail(c, RT_E_INVALID, "occluded: null device pointer");
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
-    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), true, false, d_rays, n, nullptr, d_out, r.d_counters, st));
     return RT_OK;
 }
@@ -374,7 +374,7 @@ int rt_shadow_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
     if (!lp || (n && (!d_rays || !d_hits || !d_lit))) return fail(c, RT_E_INVALID, "shadow: null pointer");
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
-    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_shadow(c->dev_scene(r), c->mode(), d_rays, d_hits, n, lp[0], lp[1], lp[2], d_srays, d_lit, st));
     return RT_OK;
 }
@@ -386,7 +386,7 @@ int rt_bounce_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
     if (n && (!d_rays || !d_hits || !d_out)) return fail(c, RT_E_INVALID, "bounce: null device pointer");
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
-    hipStream_t st = stream ? (hipStream_t)stream : r.stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_bounce(c->dev_scene(r), d_rays, d_hits, n, key0, seed, d_out, st));
     return RT_OK;
 }
@@ -410,7 +410,7 @@ int rt_sync(rt_ctx* c, int slot) {
     c->err.clear();
     if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
     RT_HIP(c, hipSetDevice(c->reps[slot].device));
-    RT_HIP(c, hipStreamSynchronize(c->reps[slot].stream));
+    RT_HIP(c, hipDeviceSynchronize());     // *_dev stages may have been enqueued on any stream
     return RT_OK;
 }
 
@@ -434,7 +434,7 @@ int rt_trace_primary(rt_ctx* c, uint32_t w, uint32_t h, rt_hit* host_out) {
         const size_t bytes = (size_t)rows * w * sizeof(rt_hit);
         RT_HIP_SLOT(r, hipSetDevice(r.device));
         if (bytes > r.out_cap) {
-            if (r.d_out) hipFree(r.d_out);
+            if (r.d_out) (void)hipFree(r.d_out);
             r.d_out = nullptr; r.out_cap = 0;
             RT_HIP_SLOT(r, hipMalloc(&r.d_out, bytes));
             r.out_cap = bytes;
@@ -464,13 +464,13 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
         const uint64_t chunk = std::min<uint64_t>(kChunkRays, e - b);
         RT_HIP_SLOT(r, hipSetDevice(r.device));
         if (chunk * sizeof(rt_ray) > r.rays_cap) {
-            if (r.d_rays) hipFree(r.d_rays);
+            if (r.d_rays) (void)hipFree(r.d_rays);
             r.d_rays = nullptr; r.rays_cap = 0;
             RT_HIP_SLOT(r, hipMalloc(&r.d_rays, chunk * sizeof(rt_ray)));
             r.rays_cap = chunk * sizeof(rt_ray);
         }
         if (chunk * osz > r.out_cap) {
-            if (r.d_out) hipFree(r.d_out);
+            if (r.d_out) (void)hipFree(r.d_out);
             r.d_out = nullptr; r.out_cap = 0;
             RT_HIP_SLOT(r, hipMalloc(&r.d_out, chunk * osz));
             r.out_cap = chunk * osz;

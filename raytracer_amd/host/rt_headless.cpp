@@ -1,0 +1,61 @@
+// rt_headless.cpp -- headless stand-in for Application::run + VkRenderer::drawFrame
+// (src/application/Application.cpp:15-21, src/vulkan/VkRenderer.cpp:1287-1374): builds the reference's
+// Cornell scene and default camera, traces one frame of primary rays through the C ABI and writes a PPM
+// that visualises the hit buffer (primitive id + distance).  Error handling mirrors src/main.cpp:5-17.
+//
+// usage: rt_headless [width height [out.ppm]]
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "raytracer.hpp"
+
+int main(int argc, char** argv) {
+    try {
+        const uint32_t w = argc > 2 ? (uint32_t)std::atoi(argv[1]) : 1200;     // Config::INIT_WINDOW_WIDTH/HEIGHT
+        const uint32_t h = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1000;     // (src/globals/globals.h:12-13)
+        const char* path = argc > 3 ? argv[3] : "frame.ppm";
+
+        std::vector<rt::Triangle> tris(rt_gen_cornell_triangles(nullptr, 0));
+        rt_gen_cornell_triangles(tris.data(), (uint32_t)tris.size());
+        std::vector<rt::Sphere> spheres(rt_gen_cornell_spheres(nullptr, 0));
+        rt_gen_cornell_spheres(spheres.data(), (uint32_t)spheres.size());
+        std::vector<rt::Light> lights;                                         // VkRenderer.cpp:252-258: none
+
+        rt::Engine engine({0});
+        engine.upload(tris, spheres, lights);
+        rt::CameraUBO cam;
+        const float pos[3] = {0.0f, 4.0f, 1.0f}, look[3] = {0.0f, 0.0f, 1.0f};  // VkRenderer.cpp:3-12
+        rt_camera_look_at(pos, look, 45.0f, (float)w / (float)h, &cam);
+        engine.setCamera(&cam);
+
+        std::vector<rt_hit> hits((size_t)w * h);
+        engine.tracePrimary(w, h, hits.data());
+
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error(std::string("failed to open ") + path);
+        f << "P6\n" << w << " " << h << "\n255\n";
+        size_t n_hit = 0;
+        for (const rt_hit& hit : hits) {
+            unsigned char rgb[3] = {0, 0, 0};
+            if (hit.prim != RT_MISS) {
+                ++n_hit;
+                const uint32_t id = (hit.prim & RT_SPHERE_BIT) ? 100u + (hit.prim & ~RT_SPHERE_BIT) : hit.prim;
+                const float shade = 1.0f / (1.0f + 0.15f * hit.t);
+                rgb[0] = (unsigned char)(255 * shade * (0.35f + 0.65f * ((id * 37u) % 7u) / 6.0f));
+                rgb[1] = (unsigned char)(255 * shade * (0.35f + 0.65f * ((id * 17u) % 5u) / 4.0f));
+                rgb[2] = (unsigned char)(255 * shade * (0.35f + 0.65f * ((id * 11u) % 3u) / 2.0f));
+            }
+            f.write(reinterpret_cast<const char*>(rgb), 3);
+        }
+        const rt_scene_stats st = engine.stats();
+        std::cout << "traced " << w << "x" << h << " primary rays, " << n_hit << " hits, " << st.n_tris << " triangles, "
+                  << st.n_spheres << " spheres -> " << path << std::endl;
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << std::endl;
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

@@ -376,3 +376,19 @@ def test_stripe_sharding_reassembles_the_full_frame(renderer, torch_dev):
         img = cat.index_select(0, rd.gather_index(rd.stripe_plan(h, world, 0, sh), "cuda"))
         torch.cuda.synchronize()
         assert to_np(img.reshape(-1), rt.HIT).tobytes() == to_np(full, rt.HIT).tobytes(), (world, sh)
+
+
+def test_cpp_headless_harness(tmp_path):
+    """The C++ host layer (raytracer_amd/host): same ABI, std::runtime_error convention, PPM out."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "raytracer_amd", "host", "rt_headless")
+    if not os.path.exists(exe):
+        pytest.skip("rt_headless not built")
+    out = tmp_path / "f.ppm"
+    p = subprocess.run([exe, "64", "48", str(out)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "3072 hits" in p.stdout and "12 triangles" in p.stdout
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n64 48\n255\n") and len(data) == len(b"P6\n64 48\n255\n") + 64 * 48 * 3
+    p = subprocess.run([exe, "0", "0", str(out)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "empty image" in p.stderr          # EXIT_FAILURE + message, as src/main.cpp:8-14
