@@ -76,6 +76,9 @@ typedef struct {
     uint64_t nodes;            /* N: interior nodes fetched */
     uint64_t tri_tests;        /* T: triangle tests */
     uint64_t sphere_tests;
+    uint64_t wave_max_nodes;   /* sum over waves of the per-wave maximum of `nodes` (divergence probe) */
+    uint64_t wave_max_tris;    /* same for triangle tests */
+    uint64_t waves;
 } rt_counters;
 
 /* ---- life cycle --------------------------------------------------------------------------------

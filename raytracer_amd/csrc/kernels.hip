@@ -20,6 +20,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr float kEps = 1e-6f;              // frag.glsl:131
+constexpr int kDone = (int)0x80000000;   // stack-bottom sentinel (never a valid leaf reference: first tri < 2^28)
 constexpr uint32_t kKeyFlip = 0x80000000u; // tie-break key = prim ^ kKeyFlip: spheres sort before triangles
 
 struct f3 { float x, y, z; };
@@ -127,10 +128,13 @@ __device__ __forceinline__ void trace_bvh2(const DevScene& s, f3 o, f3 d, float 
     const float4* __restrict__ tris = s.tris;
     const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const f3 od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
-    int sp = 0;
+    // while-while traversal: every lane walks interior nodes (popping when both children miss) until it
+    // holds a leaf or is done; then the wave intersects leaves together.  kDone sits at the stack bottom.
+    stk[0] = kDone;
+    int sp = 1;
     int node = 0;
-    for (;;) {
-        if (node >= 0) {
+    while (node != kDone) {
+        while (node >= 0) {
             const float4* np = nodes + (size_t)node * 4;
             float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             if (COUNT) { ++c.nodes; c.box += 2; }
@@ -146,18 +150,19 @@ __device__ __forceinline__ void trace_bvh2(const DevScene& s, f3 o, f3 d, float 
             float tf1 = fminf(fminf(fmaxf(b0, b1), fmaxf(b2, b3)), fminf(fmaxf(b4, b5), b.t));
             bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
             int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 | h1) {
-                if (h0 & h1) {
-                    bool sw = tn1 < tn0;
-                    stk[sp * kBlock] = sw ? c0 : c1;
-                    ++sp;
-                    node = sw ? c1 : c0;
-                } else {
-                    node = h0 ? c0 : c1;
-                }
-                continue;
+            if (h0 & h1) {
+                bool sw = tn1 < tn0;
+                stk[sp * kBlock] = sw ? c0 : c1;
+                ++sp;
+                node = sw ? c1 : c0;
+            } else if (h0 | h1) {
+                node = h0 ? c0 : c1;
+            } else {
+                --sp;
+                node = stk[sp * kBlock];
             }
-        } else {
+        }
+        if (node != kDone) {
             uint32_t ref = ~(uint32_t)node;
             uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; ++k) {
@@ -169,10 +174,9 @@ __device__ __forceinline__ void trace_bvh2(const DevScene& s, f3 o, f3 d, float 
                 if (COUNT) ++c.tris;
             }
             if (ANY && b.t < tmax) return;
+            --sp;
+            node = stk[sp * kBlock];
         }
-        if (sp == 0) return;
-        --sp;
-        node = stk[sp * kBlock];
     }
 }
 
@@ -197,14 +201,24 @@ __device__ __forceinline__ float4 pack_hit(const Best& b, float tmax) {
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const Counters& c, bool active, unsigned long long* g) {
     if (!COUNT) return;
-    uint32_t v[kNumCounters] = { active ? 1u : 0u, c.box, c.nodes, c.tris, c.spheres };
+    uint32_t v[5] = { active ? 1u : 0u, c.box, c.nodes, c.tris, c.spheres };
     #pragma unroll
-    for (int k = 0; k < kNumCounters; ++k) {
+    for (int k = 0; k < 5; ++k) {
         uint32_t x = v[k];
         #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
     }
+    // divergence probes: per-wave maxima of nodes / triangle tests (what a lock-step wave has to sit through)
+    uint32_t m[2] = { c.nodes, c.tris };
+    #pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        uint32_t x = m[k];
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x = max(x, (uint32_t)__shfl_down(x, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g[5 + k], (unsigned long long)x);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g[7], 1ull);
 }
 
 // sphere 0 has key 0, the same as "nothing yet": any-hit tests must look at t, not key
@@ -215,7 +229,7 @@ template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                   float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                   unsigned long long* counters) {
-    __shared__ int stack[MODE == kBvh2 ? kStackDepth * kBlock : 1];
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < n;
     Counters c = { 0, 0, 0, 0 };
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
                                                     uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
                                                     uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
                                                     float4* __restrict__ hits, unsigned long long* counters) {
-    __shared__ int stack[MODE == kBvh2 ? kStackDepth * kBlock : 1];
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t tile = wave / spp, smp = wave - tile * spp;
@@ -307,7 +321,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __restrict__ rays,
                                                    const float4* __restrict__ hits, uint64_t n, float lx, float ly,
                                                    float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
-    __shared__ int stack[MODE == kBvh2 ? kStackDepth * kBlock : 1];
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
@@ -382,6 +396,10 @@ __global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __r
     out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
 }
 
+// LDS for the per-lane stacks: sentinel + one entry per BVH level (+1 spare), [entry][thread]
+inline size_t stack_bytes(const DevScene& s, int mode) {
+    return mode == kBvh2 ? (size_t)(s.stack_depth + 2) * kBlock * sizeof(int) : 0;
+}
 inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -391,7 +409,7 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
     if (n == 0) return hipSuccess;
     dim3 g(grid_for(n)), b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
-#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace<M, A, C>), g, b, 0, st, s, d_rays, n, hits, d_occ, d_counters)
+#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace<M, A, C>), g, b, stack_bytes(s, M), st, s, d_rays, n, hits, d_occ, d_counters)
     if (mode == kBrute) {
         if (any_hit) { if (count) RT_LAUNCH(kBrute, true, true); else RT_LAUNCH(kBrute, true, false); }
         else         { if (count) RT_LAUNCH(kBrute, false, true); else RT_LAUNCH(kBrute, false, false); }
@@ -416,7 +434,7 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
     dim3 g((n_waves + kBlock / 64 - 1) / (kBlock / 64)), b(kBlock);
     float4* rays = reinterpret_cast<float4*>(d_rays_out);
     float4* hits = reinterpret_cast<float4*>(d_hits);
-#define RT_LAUNCH(M, C) hipLaunchKernelGGL((k_primary<M, C>), g, b, 0, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
+#define RT_LAUNCH(M, C) hipLaunchKernelGGL((k_primary<M, C>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                            jitter, tiles_x, n_waves, rays, hits, d_counters)
     if (mode == kBrute) { if (count) RT_LAUNCH(kBrute, true); else RT_LAUNCH(kBrute, false); }
     else                { if (count) RT_LAUNCH(kBvh2, true); else RT_LAUNCH(kBvh2, false); }
@@ -430,8 +448,8 @@ hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, cons
     dim3 g(grid_for(n)), b(kBlock);
     const float4* hits = reinterpret_cast<const float4*>(d_hits);
     float4* sr = reinterpret_cast<float4*>(d_shadow_rays);
-    if (mode == kBrute) hipLaunchKernelGGL((k_shadow<kBrute>), g, b, 0, st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
-    else                hipLaunchKernelGGL((k_shadow<kBvh2>), g, b, 0, st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
+    if (mode == kBrute) hipLaunchKernelGGL((k_shadow<kBrute>), g, b, stack_bytes(s, kBrute), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
+    else                hipLaunchKernelGGL((k_shadow<kBvh2>), g, b, stack_bytes(s, kBvh2), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
     return hipGetLastError();
 }
 

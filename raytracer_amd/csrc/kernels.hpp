@@ -41,6 +41,6 @@ hipError_t launch_bounce(const DevScene& s, const rt_ray* d_rays, const rt_hit* 
                          uint32_t seed, rt_ray* d_out, hipStream_t st);
 
 constexpr int kStackDepth = 32;   // per-lane traversal stack entries held in LDS
-constexpr int kNumCounters = 5;   // rays, box_tests, nodes, tri_tests, sphere_tests
+constexpr int kNumCounters = 8;   // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves
 
 }  // namespace rt

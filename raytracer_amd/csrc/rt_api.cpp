@@ -401,6 +401,7 @@ int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) {
     unsigned long long v[kNumCounters];
     RT_HIP(c, hipMemcpy(v, r.d_counters, sizeof v, hipMemcpyDeviceToHost));
     out->rays = v[0]; out->box_tests = v[1]; out->nodes = v[2]; out->tri_tests = v[3]; out->sphere_tests = v[4];
+    out->wave_max_nodes = v[5]; out->wave_max_tris = v[6]; out->waves = v[7];
     if (reset) RT_HIP(c, hipMemset(r.d_counters, 0, sizeof v));
     return RT_OK;
 }
