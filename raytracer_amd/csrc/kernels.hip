@@ -120,6 +120,54 @@ __device__ __forceinline__ float safe_rcp(float d) {
     return 1.0f / dd;
 }
 
+// One interior step for this lane: test both children, descend into the nearer hit child, push the other,
+// or pop when both miss.  Returns the next node reference.
+template <bool COUNT>
+__device__ __forceinline__ int bvh2_step(const float4* __restrict__ nodes, int node, f3 id, f3 od, float tmin, float bt,
+                                         int* __restrict__ stk, int& sp, Counters& c) {
+    const float4* np = nodes + (size_t)node * 4;
+    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    if (COUNT) { ++c.nodes; c.box += 2; }
+    float a0 = __fmaf_rn(q0.x, id.x, od.x), a1 = __fmaf_rn(q0.y, id.x, od.x);
+    float a2 = __fmaf_rn(q0.z, id.y, od.y), a3 = __fmaf_rn(q0.w, id.y, od.y);
+    float a4 = __fmaf_rn(q2.x, id.z, od.z), a5 = __fmaf_rn(q2.y, id.z, od.z);
+    float b0 = __fmaf_rn(q1.x, id.x, od.x), b1 = __fmaf_rn(q1.y, id.x, od.x);
+    float b2 = __fmaf_rn(q1.z, id.y, od.y), b3 = __fmaf_rn(q1.w, id.y, od.y);
+    float b4 = __fmaf_rn(q2.z, id.z, od.z), b5 = __fmaf_rn(q2.w, id.z, od.z);
+    float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(a2, a3)), fmaxf(fminf(a4, a5), tmin));
+    float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(a2, a3)), fminf(fmaxf(a4, a5), bt));
+    float tn1 = fmaxf(fmaxf(fminf(b0, b1), fminf(b2, b3)), fmaxf(fminf(b4, b5), tmin));
+    float tf1 = fminf(fminf(fmaxf(b0, b1), fmaxf(b2, b3)), fminf(fmaxf(b4, b5), bt));
+    bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    if (h0 & h1) {
+        bool sw = tn1 < tn0;
+        stk[sp * kBlock] = sw ? c0 : c1;
+        ++sp;
+        return sw ? c1 : c0;
+    }
+    if (h0 | h1) return h0 ? c0 : c1;
+    --sp;
+    return stk[sp * kBlock];
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void bvh2_leaf(const float4* __restrict__ tris, int node, f3 o, f3 d, float tmin, Best& b,
+                                          Counters& c) {
+    uint32_t ref = ~(uint32_t)node;
+    uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const float4* tp = tris + (size_t)(first + k) * 3;
+        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        float t, u, v;
+        if (tri_hit(o, d, mk(q0.x, q0.y, q0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), t, u, v))
+            consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
+        if (COUNT) ++c.tris;
+    }
+}
+
+// while-while traversal: every lane walks interior nodes (popping when both children miss) until it holds a
+// leaf or is done; then the wave intersects leaves together.  kDone sits at the stack bottom.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trace_bvh2(const DevScene& s, f3 o, f3 d, float tmin, float tmax, Best& b, Counters& c,
                                            int* __restrict__ stk /* this lane's column, stride kBlock */) {
@@ -128,51 +176,13 @@ __device__ __forceinline__ void trace_bvh2(const DevScene& s, f3 o, f3 d, float 
     const float4* __restrict__ tris = s.tris;
     const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const f3 od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
-    // while-while traversal: every lane walks interior nodes (popping when both children miss) until it
-    // holds a leaf or is done; then the wave intersects leaves together.  kDone sits at the stack bottom.
     stk[0] = kDone;
     int sp = 1;
     int node = 0;
     while (node != kDone) {
-        while (node >= 0) {
-            const float4* np = nodes + (size_t)node * 4;
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) { ++c.nodes; c.box += 2; }
-            float a0 = __fmaf_rn(q0.x, id.x, od.x), a1 = __fmaf_rn(q0.y, id.x, od.x);
-            float a2 = __fmaf_rn(q0.z, id.y, od.y), a3 = __fmaf_rn(q0.w, id.y, od.y);
-            float a4 = __fmaf_rn(q2.x, id.z, od.z), a5 = __fmaf_rn(q2.y, id.z, od.z);
-            float b0 = __fmaf_rn(q1.x, id.x, od.x), b1 = __fmaf_rn(q1.y, id.x, od.x);
-            float b2 = __fmaf_rn(q1.z, id.y, od.y), b3 = __fmaf_rn(q1.w, id.y, od.y);
-            float b4 = __fmaf_rn(q2.z, id.z, od.z), b5 = __fmaf_rn(q2.w, id.z, od.z);
-            float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(a2, a3)), fmaxf(fminf(a4, a5), tmin));
-            float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(a2, a3)), fminf(fmaxf(a4, a5), b.t));
-            float tn1 = fmaxf(fmaxf(fminf(b0, b1), fminf(b2, b3)), fmaxf(fminf(b4, b5), tmin));
-            float tf1 = fminf(fminf(fmaxf(b0, b1), fmaxf(b2, b3)), fminf(fmaxf(b4, b5), b.t));
-            bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 & h1) {
-                bool sw = tn1 < tn0;
-                stk[sp * kBlock] = sw ? c0 : c1;
-                ++sp;
-                node = sw ? c1 : c0;
-            } else if (h0 | h1) {
-                node = h0 ? c0 : c1;
-            } else {
-                --sp;
-                node = stk[sp * kBlock];
-            }
-        }
+        while (node >= 0) node = bvh2_step<COUNT>(nodes, node, id, od, tmin, b.t, stk, sp, c);
         if (node != kDone) {
-            uint32_t ref = ~(uint32_t)node;
-            uint32_t first = ref >> 3, cnt = (ref & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4* tp = tris + (size_t)(first + k) * 3;
-                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                float t, u, v;
-                if (tri_hit(o, d, mk(q0.x, q0.y, q0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), t, u, v))
-                    consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
-                if (COUNT) ++c.tris;
-            }
+            bvh2_leaf<COUNT>(tris, node, o, d, tmin, b, c);
             if (ANY && b.t < tmax) return;
             --sp;
             node = stk[sp * kBlock];
@@ -243,6 +253,105 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
         else     hits[i] = pack_hit(b, r1.w);
     }
     flush_counters<COUNT>(c, active, counters);
+}
+
+// Ray-buffer closest-hit / any-hit with in-wave refill ("strip" kernel).  Incoherent rays finish at very
+// different times (C3 bounce rays: 30 nodes on average, 65 for the slowest lane of a wave), so a lock-step
+// wave idles most lanes.  Here a wave owns a contiguous strip of `strip` rays; whenever at least `refill`
+// lanes are idle they take the next rays of the strip (rank by mbcnt over the idle ballot: coalesced reads,
+// no atomics), while the other lanes keep their traversal state.  Each lane writes its hit when it finishes.
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
+                                                        uint32_t strip, int refill, int tth,
+                                                        float4* __restrict__ hits, uint8_t* __restrict__ occ,
+                                                        unsigned long long* counters) {
+    extern __shared__ int stack[];
+    int* stk = stack + threadIdx.x;
+    const float4* __restrict__ nodes = s.nodes;
+    const float4* __restrict__ tris = s.tris;
+    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint64_t cursor = wave * strip;                                   // wave-uniform
+    const uint64_t end = (cursor + strip < n) ? cursor + strip : n;
+    stk[0] = kDone;
+    int node = kDone, sp = 1;
+    uint64_t my = 0;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 0), id = mk(0, 0, 0), od = mk(0, 0, 0);
+    float tmin = 0.0f, tmax = 0.0f;
+    Best b = { 0.0f, 0.0f, 0.0f, 0u };
+    Counters c = { 0, 0, 0, 0 };
+    uint32_t n_mine = 0;
+    for (;;) {
+        const bool idle = node == kDone;
+        const unsigned long long im = __ballot(idle);
+        const int n_idle = __popcll(im);
+        if (cursor < end && n_idle >= refill) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+            const uint64_t cand = cursor + rank;
+            if (idle && cand < end) {
+                my = cand;
+                const float4* rp = reinterpret_cast<const float4*>(rays + my);
+                float4 r0 = rp[0], r1 = rp[1];
+                o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
+                b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
+                if (COUNT) ++n_mine;
+                bool go = tmax > tmin;
+                if (go) {
+                    spheres_pass<COUNT>(s, o, d, tmin, b, c);
+                    go = !(ANY && b.t < tmax) && s.n_nodes != 0;
+                }
+                if (go) {
+                    id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+                    od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+                    node = 0; sp = 1;
+                } else {
+                    if (ANY) occ[my] = b.t < tmax ? 1 : 0;
+                    else     hits[my] = pack_hit(b, tmax);
+                }
+            }
+            cursor += (uint64_t)n_idle;
+        }
+        const bool live = node != kDone;
+        if (__ballot(live) == 0ull) {
+            if (cursor >= end) break;
+            continue;
+        }
+        // if-if scheduling: per round every lane does at most ONE interior step and ONE triangle test, so no
+        // lane waits for the slowest lane's whole descent.  The triangle block is skipped (wave-uniform
+        // branch) until at least `tth` lanes hold a leaf or no lane has interior work left.
+        const bool need_i = node >= 0;
+        const unsigned long long mi = __ballot(need_i);
+        if (need_i) node = bvh2_step<COUNT>(nodes, node, id, od, tmin, b.t, stk, sp, c);
+        const bool need_t = node < 0 && node != kDone;
+        const unsigned long long mt = __ballot(need_t);
+        if (__popcll(mt) >= tth || mi == 0ull) {
+            if (need_t) {
+                const uint32_t ref = ~(uint32_t)node;              // (first << 3) | (remaining - 1)
+                const float4* tp = tris + (size_t)(ref >> 3) * 3;
+                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                float t, u, v;
+                if (tri_hit(o, d, mk(q0.x, q0.y, q0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), t, u, v))
+                    consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
+                if (COUNT) ++c.tris;
+                if (ANY && b.t < tmax) { node = kDone; sp = 1; }
+                else if (ref & 7u) node = (int)~(ref + 7u);          // next triangle of the leaf: first+1, remaining-1
+                else { --sp; node = stk[sp * kBlock]; }
+            }
+        }
+        if (live && node == kDone) {
+            if (ANY) occ[my] = b.t < tmax ? 1 : 0;
+            else     hits[my] = pack_hit(b, tmax);
+        }
+    }
+    if (COUNT) {
+        uint32_t v[5] = { n_mine, c.box, c.nodes, c.tris, c.spheres };
+        #pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint32_t x = v[k];
+            #pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[k], (unsigned long long)x);
+        }
+    }
 }
 
 // Primary rays (frag.glsl:89-128) fused with traceRay.  One wave = one 8x8 pixel tile for one sample.
@@ -405,10 +514,22 @@ inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlo
 }  // namespace
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
-                        rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st) {
+                        rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
+                        uint32_t strip, int refill) {
     if (n == 0) return hipSuccess;
-    dim3 g(grid_for(n)), b(kBlock);
+    dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
+    if (mode == kBvh2 && strip >= 64) {
+        // strip kernel: one wave per `strip` rays
+        const uint64_t n_waves = (n + strip - 1) / strip;
+        dim3 g((uint32_t)((n_waves + kBlock / 64 - 1) / (kBlock / 64)));
+#define RT_LAUNCH(A, C) hipLaunchKernelGGL((k_trace_strip<A, C>), g, b, stack_bytes(s, kBvh2), st, s, d_rays, n, strip, refill & 0xff, refill >> 8, hits, d_occ, d_counters)
+        if (any_hit) { if (count) RT_LAUNCH(true, true); else RT_LAUNCH(true, false); }
+        else         { if (count) RT_LAUNCH(false, true); else RT_LAUNCH(false, false); }
+#undef RT_LAUNCH
+        return hipGetLastError();
+    }
+    dim3 g(grid_for(n));
 #define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace<M, A, C>), g, b, stack_bytes(s, M), st, s, d_rays, n, hits, d_occ, d_counters)
     if (mode == kBrute) {
         if (any_hit) { if (count) RT_LAUNCH(kBrute, true, true); else RT_LAUNCH(kBrute, true, false); }

@@ -27,7 +27,8 @@ struct DevCamera {
 enum TraceMode { kBrute = 1, kBvh2 = 2 };
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
-                        rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st);
+                        rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
+                        uint32_t strip /* rays per wave, 0 = one ray per lane */, int refill /* idle lanes that trigger a refill */);
 
 hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, bool count, uint32_t w, uint32_t h,
                           uint32_t y0, uint32_t rows, uint32_t stripe_h, uint32_t stripe_step, uint32_t spp,

@@ -55,6 +55,8 @@ struct rt_ctx {
     int counters = 0;
     int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2
     int max_leaf = 4;
+    uint32_t strip = 512;       // rays per wave in the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
+    int refill = 32 | (16 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
     // scene
     bool has_scene = false, has_camera = false;
     rt_scene_stats stats{};
@@ -184,6 +186,8 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) {
         case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
         case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
         case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;
+        case RT_OPT_STRIP:       if (v != 0 && (v < 64 || v > (1 << 24))) return fail(c, RT_E_INVALID, "RT_OPT_STRIP: 0 or 64..2^24"); c->strip = (uint32_t)v; return RT_OK;
+        case RT_OPT_REFILL:      if ((v & 0xff) < 1 || (v & 0xff) > 64 || (v >> 8) > 64) return fail(c, RT_E_INVALID, "RT_OPT_REFILL: low byte 1..64 idle lanes, bits 8.. = leaf-vote threshold 0..64"); c->refill = (int)v; return RT_OK;
         default: return fail(c, RT_E_INVALID, "unknown option key");
     }
 }
@@ -352,7 +356,7 @@ int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* 
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
-    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), false, c->counters != 0, d_rays, n, d_hits, nullptr, r.d_counters, st));
+    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), false, c->counters != 0, d_rays, n, d_hits, nullptr, r.d_counters, st, c->strip, c->refill));
     return RT_OK;
 }
 
@@ -363,7 +367,7 @@ int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
-    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), true, false, d_rays, n, nullptr, d_out, r.d_counters, st));
+    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), true, false, d_rays, n, nullptr, d_out, r.d_counters, st, c->strip, c->refill));
     return RT_OK;
 }
 
@@ -481,7 +485,7 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
             RT_HIP_SLOT(r, hipMemcpyAsync(r.d_rays, rays + i, m * sizeof(rt_ray), hipMemcpyHostToDevice, r.stream));
             RT_HIP_SLOT(r, launch_trace(c->dev_scene(r), mode, any_hit, false, static_cast<const rt_ray*>(r.d_rays), m,
                                         any_hit ? nullptr : static_cast<rt_hit*>(r.d_out),
-                                        any_hit ? static_cast<uint8_t*>(r.d_out) : nullptr, r.d_counters, r.stream));
+                                        any_hit ? static_cast<uint8_t*>(r.d_out) : nullptr, r.d_counters, r.stream, c->strip, c->refill));
             RT_HIP_SLOT(r, hipMemcpyAsync(static_cast<char*>(out) + i * osz, r.d_out, m * osz, hipMemcpyDeviceToHost, r.stream));
             RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
         }
