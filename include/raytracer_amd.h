@@ -48,7 +48,8 @@ enum {
 
 /* rt_set_option keys */
 enum {
-    RT_OPT_TRAVERSAL = 1,   /* 0 auto (default), 1 brute force (the reference's loop), 2 BVH */
+    RT_OPT_TRAVERSAL = 1,   /* 0 auto (default), 1 brute force (the reference's loop), 2 BVH2 nodes, 3 BVH4q nodes
+                               (the node layout is chosen at rt_scene_upload: set this first) */
     RT_OPT_BVH_THREADS = 2, /* host threads for the BVH build; 0 = hardware concurrency capped at 16 */
     RT_OPT_COUNTERS = 3,    /* 1: *_dev closest-hit launches run the instrumented kernel and accumulate rt_counters */
     RT_OPT_PAD_LOG2 = 4,    /* BVH boxes are padded by max|coordinate| * 2^-value (default 15); takes effect at upload */

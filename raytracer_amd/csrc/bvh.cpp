@@ -272,4 +272,140 @@ void flatten_bvh2(const BuildResult& b, float pad, FlatBvh2& out) {
     }
 }
 
+uint32_t bvh2_stack_need(const BuildResult& b) {
+    if (b.nodes.empty()) return 0;
+    uint32_t need = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st;      // (node, entries on the stack when it is entered)
+    st.push_back({ 0u, 0u });
+    while (!st.empty()) {
+        auto [i, d] = st.back(); st.pop_back();
+        need = std::max(need, d);
+        const BuildNode& nd = b.nodes[i];
+        if (!nd.count) { st.push_back({ nd.left, d + 1 }); st.push_back({ nd.right, d + 1 }); }
+    }
+    return need;
+}
+
+namespace {
+
+// Children of a wide node: start from the two children of `i` and keep opening the interior child with
+// the largest surface area until there are four (or only leaves are left).
+int gather4(const BuildResult& b, uint32_t i, uint32_t out[4]) {
+    const BuildNode& nd = b.nodes[i];
+    int n = 0;
+    out[n++] = nd.left; out[n++] = nd.right;
+    while (n < 4) {
+        int best = -1; float best_area = -1.f;
+        for (int k = 0; k < n; ++k) {
+            const BuildNode& c = b.nodes[out[k]];
+            if (c.count) continue;
+            float a = c.box.half_area();
+            if (a > best_area) { best_area = a; best = k; }
+        }
+        if (best < 0) break;
+        const BuildNode& c = b.nodes[out[best]];
+        out[best] = c.left;
+        out[n++] = c.right;
+    }
+    return n;
+}
+
+}  // namespace
+
+void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
+    out.nodes.clear(); out.tri_order.clear();
+    out.n_nodes = 0; out.n_leaves = b.n_leaves; out.depth = 0; out.stack_need = 0;
+    if (b.nodes.empty()) return;
+
+    struct Wide { uint32_t src; uint32_t child[4]; int n; };
+    std::vector<Wide> wide;
+    std::vector<int32_t> ref(b.nodes.size(), 0);       // reference of every build node that becomes a child
+    out.tri_order.reserve(b.prim_index.size());
+
+    // DFS pre-order over wide nodes; (build node, depth, stack entries at entry)
+    struct Item { uint32_t src, depth, stack; };
+    std::vector<Item> st;
+    auto emit_leaf = [&](uint32_t i) {
+        const BuildNode& nd = b.nodes[i];
+        ref[i] = leaf_ref((uint32_t)out.tri_order.size(), nd.count);
+        for (uint32_t k = 0; k < nd.count; ++k) out.tri_order.push_back(b.prim_index[nd.first + k]);
+    };
+    if (b.nodes[0].count) {
+        // the root is a leaf: one wide node with a single child
+        emit_leaf(0);
+        Wide w{}; w.src = 0; w.n = 1; w.child[0] = 0;
+        wide.push_back(w);
+        out.depth = 1;
+    } else {
+        st.push_back({ 0u, 1u, 0u });
+        while (!st.empty()) {
+            Item it = st.back(); st.pop_back();
+            Wide w{}; w.src = it.src;
+            w.n = gather4(b, it.src, w.child);
+            ref[it.src] = (int32_t)wide.size();
+            wide.push_back(w);
+            out.depth = std::max(out.depth, it.depth);
+            // a visit may push up to n-1 siblings before descending
+            out.stack_need = std::max(out.stack_need, it.stack + (uint32_t)(w.n - 1));
+            for (int k = w.n - 1; k >= 0; --k) {
+                if (b.nodes[w.child[k]].count == 0) st.push_back({ w.child[k], it.depth + 1, it.stack + (uint32_t)(w.n - 1) });
+            }
+            // leaves are emitted when the wide node is written (below) to keep triangles of one node adjacent
+        }
+    }
+    // second pass in the same order: leaves' triangle ranges (children of node k stay adjacent in memory)
+    if (!b.nodes[0].count)
+        for (const Wide& w : wide)
+            for (int k = 0; k < w.n; ++k)
+                if (b.nodes[w.child[k]].count) emit_leaf(w.child[k]);
+
+    out.n_nodes = (uint32_t)wide.size();
+    out.nodes.assign((size_t)out.n_nodes * 16, 0u);
+    for (uint32_t wi = 0; wi < out.n_nodes; ++wi) {
+        const Wide& w = wide[wi];
+        uint32_t* q = &out.nodes[(size_t)wi * 16];
+        float lo[4][3], hi[4][3], org[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, top[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (int k = 0; k < w.n; ++k) {
+            const Aabb& bx = b.nodes[w.child[k]].box;
+            for (int a = 0; a < 3; ++a) {
+                lo[k][a] = bx.lo[a] - pad; hi[k][a] = bx.hi[a] + pad;
+                org[a] = std::min(org[a], lo[k][a]); top[a] = std::max(top[a], hi[k][a]);
+            }
+        }
+        uint32_t ebyte[3];
+        for (int a = 0; a < 3; ++a) {
+            // smallest power of two 2^e with origin + 255 * 2^e >= top (checked in double; all inputs are floats)
+            double ext = (double)top[a] - (double)org[a];
+            int e = -126;
+            if (ext > 0.0) { int ee; std::frexp(ext / 255.0, &ee); e = std::max(ee, -126); }
+            while (std::ldexp(255.0, e) < ext) ++e;
+            if (e > 127) e = 127;
+            ebyte[a] = (uint32_t)(e + 127);
+            const double sc = std::ldexp(1.0, e);
+            for (int k = 0; k < w.n; ++k) {
+                double ql = std::floor(((double)lo[k][a] - (double)org[a]) / sc);
+                double qh = std::ceil(((double)hi[k][a] - (double)org[a]) / sc);
+                if (ql < 0) ql = 0;
+                if (ql > 255) ql = 255;
+                if (qh > 255) qh = 255;
+                if (qh < 0) qh = 0;
+                // guard the conservative property against the fp32 arithmetic the kernel uses
+                while (ql > 0 && (double)org[a] + ql * sc > (double)lo[k][a]) ql -= 1;
+                while (qh < 255 && (double)org[a] + qh * sc < (double)hi[k][a]) qh += 1;
+                const uint32_t l8 = (uint32_t)ql, h8 = (uint32_t)qh;
+                const int lo_word = 8 + a;                       // q2.x/y/z = lo planes
+                const int hi_word = (a == 0) ? 11 : 12 + (a - 1);  // q2.w = hi.x, q3.x = hi.y, q3.y = hi.z
+                q[lo_word] |= l8 << (8 * k);
+                q[hi_word] |= h8 << (8 * k);
+            }
+        }
+        std::memcpy(&q[0], &org[0], 4); std::memcpy(&q[1], &org[1], 4); std::memcpy(&q[2], &org[2], 4);
+        q[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16) | ((uint32_t)w.n << 24);
+        for (int k = 0; k < 4; ++k) {
+            int32_t r = (k < w.n) ? ref[w.child[k]] : leaf_ref(0, 1);
+            std::memcpy(&q[4 + k], &r, 4);
+        }
+    }
+}
+
 }  // namespace rt

@@ -63,4 +63,25 @@ static constexpr int32_t kEmptyLeaf = 0x7fffffff;   // never visited: its box is
 
 void flatten_bvh2(const BuildResult& b, float pad, FlatBvh2& out);
 
+// ---- 4-wide, quantised layout ("BVH4q") ---------------------------------------------------------
+// Incoherent traversal on CDNA4 is bound by the vector-memory path (one pass per cache line per load
+// instruction), not by VALU, so the node packs FOUR children into the 64 B that BVH2 spends on two:
+//   q0 = (origin.x, origin.y, origin.z, bits: ex | ey<<8 | ez<<16 | n_children<<24)   ex.. = biased fp32 exponents
+//   q1 = child references 0..3 (same encoding as BVH2)
+//   q2 = (lo.x[0..3], lo.y[0..3], lo.z[0..3], hi.x[0..3])     one byte per child, plane = origin + 2^e * q
+//   q3 = (hi.y[0..3], hi.z[0..3], 0, 0)                        only the first 8 bytes are fetched
+// Quantisation rounds lo down and hi up from the PADDED child box, so every quantised box contains the box
+// BVH2 would have used: traversal stays conservative and results stay identical to the brute-force loop.
+struct FlatBvh4q {
+    std::vector<uint32_t> nodes;      // 16 words per node
+    std::vector<uint32_t> tri_order;
+    uint32_t n_nodes = 0, n_leaves = 0, depth = 0;
+    uint32_t stack_need = 0;          // exact bound on traversal-stack entries (excluding the sentinel)
+};
+
+void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out);
+
+// exact bound on the BVH2 traversal stack (entries pushed along the worst root-to-leaf path)
+uint32_t bvh2_stack_need(const BuildResult& b);
+
 }  // namespace rt

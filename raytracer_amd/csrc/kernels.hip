@@ -120,35 +120,106 @@ __device__ __forceinline__ float safe_rcp(float d) {
     return 1.0f / dd;
 }
 
-// One interior step for this lane: test both children, descend into the nearer hit child, push the other,
-// or pop when both miss.  Returns the next node reference.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Per-ray slab constants, duplicated into register pairs so that the (lo, hi) planes of one axis go through
+// one v_pk_fma_f32: t = plane * idir + (-o * idir).
+struct Slab { v2f ix, iy, iz, ox, oy, oz; };
+__device__ __forceinline__ Slab make_slab(f3 o, f3 d) {
+    const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const f3 od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+    Slab s;
+    s.ix = (v2f){ id.x, id.x }; s.iy = (v2f){ id.y, id.y }; s.iz = (v2f){ id.z, id.z };
+    s.ox = (v2f){ od.x, od.x }; s.oy = (v2f){ od.y, od.y }; s.oz = (v2f){ od.z, od.z };
+    return s;
+}
+
+// One interior step for this lane, branch-free: test both children, descend into the nearer hit child and
+// push the other, or pop when both miss.  The would-be-popped entry is read up front (its latency hides
+// under the node fetch) and the far child is always written to the free slot; only `sp` decides what counts.
 template <bool COUNT>
-__device__ __forceinline__ int bvh2_step(const float4* __restrict__ nodes, int node, f3 id, f3 od, float tmin, float bt,
+__device__ __forceinline__ int bvh2_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin, float bt,
                                          int* __restrict__ stk, int& sp, Counters& c) {
     const float4* np = nodes + (size_t)node * 4;
+    const int popped = stk[(sp - 1) * kBlock];
     float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
     if (COUNT) { ++c.nodes; c.box += 2; }
-    float a0 = __fmaf_rn(q0.x, id.x, od.x), a1 = __fmaf_rn(q0.y, id.x, od.x);
-    float a2 = __fmaf_rn(q0.z, id.y, od.y), a3 = __fmaf_rn(q0.w, id.y, od.y);
-    float a4 = __fmaf_rn(q2.x, id.z, od.z), a5 = __fmaf_rn(q2.y, id.z, od.z);
-    float b0 = __fmaf_rn(q1.x, id.x, od.x), b1 = __fmaf_rn(q1.y, id.x, od.x);
-    float b2 = __fmaf_rn(q1.z, id.y, od.y), b3 = __fmaf_rn(q1.w, id.y, od.y);
-    float b4 = __fmaf_rn(q2.z, id.z, od.z), b5 = __fmaf_rn(q2.w, id.z, od.z);
-    float tn0 = fmaxf(fmaxf(fminf(a0, a1), fminf(a2, a3)), fmaxf(fminf(a4, a5), tmin));
-    float tf0 = fminf(fminf(fmaxf(a0, a1), fmaxf(a2, a3)), fminf(fmaxf(a4, a5), bt));
-    float tn1 = fmaxf(fmaxf(fminf(b0, b1), fminf(b2, b3)), fmaxf(fminf(b4, b5), tmin));
-    float tf1 = fminf(fminf(fmaxf(b0, b1), fmaxf(b2, b3)), fminf(fmaxf(b4, b5), bt));
-    bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-    if (h0 & h1) {
-        bool sw = tn1 < tn0;
-        stk[sp * kBlock] = sw ? c0 : c1;
-        ++sp;
-        return sw ? c1 : c0;
+    v2f ax = __builtin_elementwise_fma((v2f){ q0.x, q0.y }, sl.ix, sl.ox);
+    v2f ay = __builtin_elementwise_fma((v2f){ q0.z, q0.w }, sl.iy, sl.oy);
+    v2f az = __builtin_elementwise_fma((v2f){ q2.x, q2.y }, sl.iz, sl.oz);
+    v2f bx = __builtin_elementwise_fma((v2f){ q1.x, q1.y }, sl.ix, sl.ox);
+    v2f by = __builtin_elementwise_fma((v2f){ q1.z, q1.w }, sl.iy, sl.oy);
+    v2f bz = __builtin_elementwise_fma((v2f){ q2.z, q2.w }, sl.iz, sl.oz);
+    float tn0 = fmaxf(fmaxf(fminf(ax.x, ax.y), fminf(ay.x, ay.y)), fmaxf(fminf(az.x, az.y), tmin));
+    float tf0 = fminf(fminf(fmaxf(ax.x, ax.y), fmaxf(ay.x, ay.y)), fminf(fmaxf(az.x, az.y), bt));
+    float tn1 = fmaxf(fmaxf(fminf(bx.x, bx.y), fminf(by.x, by.y)), fmaxf(fminf(bz.x, bz.y), tmin));
+    float tf1 = fminf(fminf(fmaxf(bx.x, bx.y), fmaxf(by.x, by.y)), fminf(fmaxf(bz.x, bz.y), bt));
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    const bool take1 = h1 & ((tn1 < tn0) | !h0);            // child 1 is the one to enter
+    const int near = take1 ? c1 : c0, far = take1 ? c0 : c1;
+    stk[sp * kBlock] = far;
+    const bool both = h0 & h1, any = h0 | h1;
+    sp += both ? 1 : (any ? 0 : -1);
+    return any ? near : popped;
+}
+
+// ---- BVH4q: four 8-bit-quantised children per 64-B node (layout: bvh.hpp) -----------------------------
+// plane = origin + 2^e * q  =>  t = q * (2^e * idir) + (origin * idir - o * idir): one cvt + one (packed) fma
+// per plane.  Hit children are sorted by entry distance (5-comparator network on (key, ref) pairs); the nearest
+// is entered, the others are pushed so that the next nearest pops first.
+__device__ __forceinline__ void cswap(uint32_t& ka, int& ra, uint32_t& kb, int& rb) {
+    const bool sw = kb < ka;
+    const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
+                                          int* __restrict__ stk, int& sp, Counters& c) {
+    const uint4* np = reinterpret_cast<const uint4*>(nodes) + (size_t)node * 4;
+    const int popped = stk[(sp - 1) * kBlock];
+    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const uint2 q3 = *reinterpret_cast<const uint2*>(np + 3);
+    const uint32_t w = q0.w, n = w >> 24;
+    if (COUNT) { ++c.nodes; c.box += n; }
+    const float idx = sl.ix.x, idy = sl.iy.x, idz = sl.iz.x;
+    const float sx = __uint_as_float((w << 23) & 0x7f800000u) * idx;
+    const float sy = __uint_as_float((w << 15) & 0x7f800000u) * idy;
+    const float sz = __uint_as_float((w << 7) & 0x7f800000u) * idz;
+    const float ax = __fmaf_rn(__uint_as_float(q0.x), idx, sl.ox.x);
+    const float ay = __fmaf_rn(__uint_as_float(q0.y), idy, sl.oy.x);
+    const float az = __fmaf_rn(__uint_as_float(q0.z), idz, sl.oz.x);
+    const v2f sx2 = (v2f){ sx, sx }, sy2 = (v2f){ sy, sy }, sz2 = (v2f){ sz, sz };
+    const v2f ax2 = (v2f){ ax, ax }, ay2 = (v2f){ ay, ay }, az2 = (v2f){ az, az };
+    uint32_t key[4];
+    int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lx = (float)((q2.x >> (8 * k)) & 0xffu), ly = (float)((q2.y >> (8 * k)) & 0xffu);
+        const float lz = (float)((q2.z >> (8 * k)) & 0xffu), hx = (float)((q2.w >> (8 * k)) & 0xffu);
+        const float hy = (float)((q3.x >> (8 * k)) & 0xffu), hz = (float)((q3.y >> (8 * k)) & 0xffu);
+        const v2f tx = __builtin_elementwise_fma((v2f){ lx, hx }, sx2, ax2);
+        const v2f ty = __builtin_elementwise_fma((v2f){ ly, hy }, sy2, ay2);
+        const v2f tz = __builtin_elementwise_fma((v2f){ lz, hz }, sz2, az2);
+        const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin0));
+        const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), bt));
+        const bool hit = (tn <= tf) & ((uint32_t)k < n);
+        key[k] = hit ? __float_as_uint(tn) : 0xffffffffu;          // tn >= tmin0 >= 0: bits order like the value
     }
-    if (h0 | h1) return h0 ? c0 : c1;
-    --sp;
-    return stk[sp * kBlock];
+    cswap(key[0], ref[0], key[1], ref[1]);
+    cswap(key[2], ref[2], key[3], ref[3]);
+    cswap(key[0], ref[0], key[2], ref[2]);
+    cswap(key[1], ref[1], key[3], ref[3]);
+    cswap(key[1], ref[1], key[2], ref[2]);
+    const int h = (key[0] != 0xffffffffu) + (key[1] != 0xffffffffu) + (key[2] != 0xffffffffu) + (key[3] != 0xffffffffu);
+    // push hits 1..h-1, farthest first: entry j lands at sp + h - 1 - j
+    if (h > 3) stk[sp * kBlock] = ref[3];
+    if (h > 2) stk[(sp + h - 3) * kBlock] = ref[2];
+    if (h > 1) stk[(sp + h - 2) * kBlock] = ref[1];
+    sp += h ? h - 1 : -1;
+    return h ? ref[0] : popped;
 }
 
 template <bool COUNT>
@@ -166,21 +237,28 @@ __device__ __forceinline__ void bvh2_leaf(const float4* __restrict__ tris, int n
     }
 }
 
+template <int MODE, bool COUNT>
+__device__ __forceinline__ int bvh_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
+                                        int* __restrict__ stk, int& sp, Counters& c) {
+    if (MODE == kBvh4q) return bvh4q_step<COUNT>(nodes, node, sl, tmin0, bt, stk, sp, c);
+    return bvh2_step<COUNT>(nodes, node, sl, tmin0, bt, stk, sp, c);
+}
+
 // while-while traversal: every lane walks interior nodes (popping when both children miss) until it holds a
 // leaf or is done; then the wave intersects leaves together.  kDone sits at the stack bottom.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ void trace_bvh2(const DevScene& s, f3 o, f3 d, float tmin, float tmax, Best& b, Counters& c,
-                                           int* __restrict__ stk /* this lane's column, stride kBlock */) {
+template <int MODE, bool ANY, bool COUNT>
+__device__ __forceinline__ void trace_bvh(const DevScene& s, f3 o, f3 d, float tmin, float tmax, Best& b, Counters& c,
+                                          int* __restrict__ stk /* this lane's column, stride kBlock */) {
     if (s.n_nodes == 0) return;
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
-    const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    const f3 od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+    const Slab sl = make_slab(o, d);
+    const float tmin0 = fmaxf(tmin, 0.0f);      // accepted hits have t > 1e-6 (frag.glsl:151) and t > 0 (:174)
     stk[0] = kDone;
     int sp = 1;
     int node = 0;
     while (node != kDone) {
-        while (node >= 0) node = bvh2_step<COUNT>(nodes, node, id, od, tmin, b.t, stk, sp, c);
+        while (node >= 0) node = bvh_step<MODE, COUNT>(nodes, node, sl, tmin0, b.t, stk, sp, c);
         if (node != kDone) {
             bvh2_leaf<COUNT>(tris, node, o, d, tmin, b, c);
             if (ANY && b.t < tmax) return;
@@ -198,7 +276,7 @@ __device__ __forceinline__ void trace_ray(const DevScene& s, f3 o, f3 d, float t
     spheres_pass<COUNT>(s, o, d, tmin, b, c);
     if (ANY && b.t < tmax) return;
     if (MODE == kBrute) trace_brute<ANY, COUNT>(s, o, d, tmin, b, c);
-    else                trace_bvh2<ANY, COUNT>(s, o, d, tmin, tmax, b, c, stk);
+    else                trace_bvh<MODE, ANY, COUNT>(s, o, d, tmin, tmax, b, c, stk);
 }
 
 // b.key == 0 can also be sphere 0 (key 0): a hit is recognised by t < tmax instead.
@@ -248,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
         float4 r0 = rp[0], r1 = rp[1];
         Best b;
         trace_ray<MODE, ANY, COUNT>(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w, b, c,
-                                    stack + (MODE == kBvh2 ? threadIdx.x : 0));
+                                    stack + (MODE != kBrute ? threadIdx.x : 0));
         if (ANY) occ[i] = found(b, r1.w) ? 1 : 0;
         else     hits[i] = pack_hit(b, r1.w);
     }
@@ -260,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 // wave idles most lanes.  Here a wave owns a contiguous strip of `strip` rays; whenever at least `refill`
 // lanes are idle they take the next rays of the strip (rank by mbcnt over the idle ballot: coalesced reads,
 // no atomics), while the other lanes keep their traversal state.  Each lane writes its hit when it finishes.
-template <bool ANY, bool COUNT>
+template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
@@ -275,8 +353,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     stk[0] = kDone;
     int node = kDone, sp = 1;
     uint64_t my = 0;
-    f3 o = mk(0, 0, 0), d = mk(0, 0, 0), id = mk(0, 0, 0), od = mk(0, 0, 0);
-    float tmin = 0.0f, tmax = 0.0f;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    Slab sl = make_slab(o, d);
+    float tmin = 0.0f, tmin0 = 0.0f, tmax = 0.0f;
     Best b = { 0.0f, 0.0f, 0.0f, 0u };
     Counters c = { 0, 0, 0, 0 };
     uint32_t n_mine = 0;
@@ -292,6 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
                 const float4* rp = reinterpret_cast<const float4*>(rays + my);
                 float4 r0 = rp[0], r1 = rp[1];
                 o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
+                tmin0 = fmaxf(tmin, 0.0f);
                 b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
                 if (COUNT) ++n_mine;
                 bool go = tmax > tmin;
@@ -300,8 +380,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
                     go = !(ANY && b.t < tmax) && s.n_nodes != 0;
                 }
                 if (go) {
-                    id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-                    od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+                    sl = make_slab(o, d);
                     node = 0; sp = 1;
                 } else {
                     if (ANY) occ[my] = b.t < tmax ? 1 : 0;
@@ -320,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
         // branch) until at least `tth` lanes hold a leaf or no lane has interior work left.
         const bool need_i = node >= 0;
         const unsigned long long mi = __ballot(need_i);
-        if (need_i) node = bvh2_step<COUNT>(nodes, node, id, od, tmin, b.t, stk, sp, c);
+        if (need_i) node = bvh_step<MODE, COUNT>(nodes, node, sl, tmin0, b.t, stk, sp, c);
         const bool need_t = node < 0 && node != kDone;
         const unsigned long long mt = __ballot(need_t);
         if (__popcll(mt) >= tth || mi == 0ull) {
@@ -387,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
         f3 o = mk(cam.px, cam.py, cam.pz);
         const float tmin = 0.0f, tmax = 1e20f;                        // :266
         Best b;
-        trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stack + (MODE == kBvh2 ? threadIdx.x : 0));
+        trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
         const size_t r = ((size_t)yl * w + x) * spp + smp;
         if (rays_out) {
             rays_out[2 * r] = make_float4(o.x, o.y, o.z, tmin);
@@ -447,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __r
     f3 so = madd3(0.001f, nn, p);                            // :326
     Best b; Counters c = { 0, 0, 0, 0 };
     const float tmax = 1e20f;
-    trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE == kBvh2 ? threadIdx.x : 0));
+    trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
     bool is_lit = true;
     if (b.t < tmax) {
         f3 dl = sub3(madd3(b.t, L, so), p);
@@ -507,7 +586,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __r
 
 // LDS for the per-lane stacks: sentinel + one entry per BVH level (+1 spare), [entry][thread]
 inline size_t stack_bytes(const DevScene& s, int mode) {
-    return mode == kBvh2 ? (size_t)(s.stack_depth + 2) * kBlock * sizeof(int) : 0;
+    return mode != kBrute ? (size_t)(s.stack_depth + 2) * kBlock * sizeof(int) : 0;
 }
 inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
@@ -519,26 +598,23 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
     if (n == 0) return hipSuccess;
     dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
-    if (mode == kBvh2 && strip >= 64) {
+    const int rf = refill & 0xff, tth = refill >> 8;
+    if (mode != kBrute && strip >= 64) {
         // strip kernel: one wave per `strip` rays
         const uint64_t n_waves = (n + strip - 1) / strip;
         dim3 g((uint32_t)((n_waves + kBlock / 64 - 1) / (kBlock / 64)));
-#define RT_LAUNCH(A, C) hipLaunchKernelGGL((k_trace_strip<A, C>), g, b, stack_bytes(s, kBvh2), st, s, d_rays, n, strip, refill & 0xff, refill >> 8, hits, d_occ, d_counters)
-        if (any_hit) { if (count) RT_LAUNCH(true, true); else RT_LAUNCH(true, false); }
-        else         { if (count) RT_LAUNCH(false, true); else RT_LAUNCH(false, false); }
+#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, stack_bytes(s, M), st, s, d_rays, n, strip, rf, tth, hits, d_occ, d_counters)
+#define RT_LAUNCH_M(M) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true); else RT_LAUNCH(M, true, false); } \
+                            else         { if (count) RT_LAUNCH(M, false, true); else RT_LAUNCH(M, false, false); } } while (0)
+        if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
         return hipGetLastError();
     }
     dim3 g(grid_for(n));
 #define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace<M, A, C>), g, b, stack_bytes(s, M), st, s, d_rays, n, hits, d_occ, d_counters)
-    if (mode == kBrute) {
-        if (any_hit) { if (count) RT_LAUNCH(kBrute, true, true); else RT_LAUNCH(kBrute, true, false); }
-        else         { if (count) RT_LAUNCH(kBrute, false, true); else RT_LAUNCH(kBrute, false, false); }
-    } else {
-        if (any_hit) { if (count) RT_LAUNCH(kBvh2, true, true); else RT_LAUNCH(kBvh2, true, false); }
-        else         { if (count) RT_LAUNCH(kBvh2, false, true); else RT_LAUNCH(kBvh2, false, false); }
-    }
+    if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
+#undef RT_LAUNCH_M
     return hipGetLastError();
 }
 
@@ -557,9 +633,10 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
     float4* hits = reinterpret_cast<float4*>(d_hits);
 #define RT_LAUNCH(M, C) hipLaunchKernelGGL((k_primary<M, C>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                            jitter, tiles_x, n_waves, rays, hits, d_counters)
-    if (mode == kBrute) { if (count) RT_LAUNCH(kBrute, true); else RT_LAUNCH(kBrute, false); }
-    else                { if (count) RT_LAUNCH(kBvh2, true); else RT_LAUNCH(kBvh2, false); }
+#define RT_LAUNCH_M(M) do { if (count) RT_LAUNCH(M, true); else RT_LAUNCH(M, false); } while (0)
+    if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
+#undef RT_LAUNCH_M
     return hipGetLastError();
 }
 
@@ -569,8 +646,9 @@ hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, cons
     dim3 g(grid_for(n)), b(kBlock);
     const float4* hits = reinterpret_cast<const float4*>(d_hits);
     float4* sr = reinterpret_cast<float4*>(d_shadow_rays);
-    if (mode == kBrute) hipLaunchKernelGGL((k_shadow<kBrute>), g, b, stack_bytes(s, kBrute), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
-    else                hipLaunchKernelGGL((k_shadow<kBvh2>), g, b, stack_bytes(s, kBvh2), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
+#define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shadow<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit)
+    if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
+#undef RT_LAUNCH_M
     return hipGetLastError();
 }
 

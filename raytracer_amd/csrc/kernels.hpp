@@ -8,7 +8,7 @@ namespace rt {
 
 // Device view of one scene replica (all pointers 16-B aligned, see DESIGN.md "Data layout").
 struct DevScene {
-    const float4* nodes;     // 4 x float4 per interior node (BVH2)
+    const float4* nodes;     // 4 x float4 per interior node (BVH2 or BVH4q, see bvh.hpp)
     const float4* tris;      // 3 x float4 per triangle in leaf order: (v0, bits id) (e1, 0) (e2, 0)
     const float4* normals;   // 3 x float4 per triangle in ORIGINAL order: n0, n1, n2
     const float4* spheres;   // (centre, radius)
@@ -24,7 +24,7 @@ struct DevCamera {
     float fx, fy, fz, pad1;
 };
 
-enum TraceMode { kBrute = 1, kBvh2 = 2 };
+enum TraceMode { kBrute = 1, kBvh2 = 2, kBvh4q = 3 };
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,

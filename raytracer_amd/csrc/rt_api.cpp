@@ -61,16 +61,18 @@ struct rt_ctx {
     bool has_scene = false, has_camera = false;
     rt_scene_stats stats{};
     DevCamera cam{};
+    uint32_t stack_need = 0;    // traversal-stack entries the uploaded tree can need
+    int layout = kBvh2;         // node layout the uploaded scene was flattened to
     int mode() const {
         if (traversal == 1) return kBrute;
-        if (traversal == 2) return kBvh2;
-        return stats.n_tris <= 32 ? kBrute : kBvh2;
+        if (traversal == 2 || traversal == 3) return layout;
+        return stats.n_tris <= 32 ? kBrute : layout;
     }
     DevScene dev_scene(const Replica& r) const {
         DevScene s;
         s.nodes = r.d_nodes; s.tris = r.d_tris; s.normals = r.d_normals; s.spheres = r.d_spheres;
         s.n_nodes = stats.n_nodes; s.n_tris = stats.n_tris; s.n_spheres = stats.n_spheres;
-        s.stack_depth = stats.max_depth;
+        s.stack_depth = stack_need;
         return s;
     }
 };
@@ -181,7 +183,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     switch (key) {
-        case RT_OPT_TRAVERSAL:   if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_TRAVERSAL: 0 auto, 1 brute, 2 bvh"); c->traversal = (int)v; return RT_OK;
+        case RT_OPT_TRAVERSAL:   if (v < 0 || v > 3) return fail(c, RT_E_INVALID, "RT_OPT_TRAVERSAL: 0 auto, 1 brute, 2 BVH2, 3 BVH4q"); c->traversal = (int)v; return RT_OK;
         case RT_OPT_BVH_THREADS: if (v < 0 || v > 256) return fail(c, RT_E_INVALID, "RT_OPT_BVH_THREADS out of range"); c->bvh_threads = (int)v; return RT_OK;
         case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
         case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
@@ -231,10 +233,30 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     build_bvh2(boxes.data(), n_tris, bp, br);
     for (const BuildNode& nd : br.nodes)
         if (nd.count > 8) return fail(c, RT_E_TOO_LARGE, "internal: leaf with more than 8 triangles (depth budget exceeded)");
-    FlatBvh2 flat;
+    // traversal option 3 asks for the 4-wide quantised layout; everything else gets BVH2 (faster today, r01d)
+    int layout = (c->traversal == 3) ? kBvh4q : kBvh2;
     const float pad = std::ldexp(std::max(maxabs, 1e-30f), -c->pad_log2);
-    flatten_bvh2(br, n_tris ? pad : 0.f, flat);
-    if (flat.depth + 1 > (uint32_t)kStackDepth) return fail(c, RT_E_TOO_LARGE, "internal: BVH deeper than the traversal stack");
+    struct { std::vector<float> nodes; std::vector<uint32_t> tri_order; uint32_t n_nodes = 0, n_leaves = 0, depth = 0, stack_need = 0; } flat;
+    if (layout == kBvh4q) {
+        FlatBvh4q f4;
+        flatten_bvh4q(br, n_tris ? pad : 0.f, f4);
+        if (f4.stack_need + 2 > 64) {
+            layout = kBvh2;                     // pathological tree: its 4-wide stack would not fit 64 KB of LDS
+        } else {
+            flat.nodes.resize(f4.nodes.size());
+            if (!f4.nodes.empty()) std::memcpy(flat.nodes.data(), f4.nodes.data(), f4.nodes.size() * 4);
+            flat.tri_order.swap(f4.tri_order);
+            flat.n_nodes = f4.n_nodes; flat.n_leaves = f4.n_leaves; flat.depth = f4.depth; flat.stack_need = f4.stack_need;
+        }
+    }
+    if (layout == kBvh2) {
+        FlatBvh2 f2;
+        flatten_bvh2(br, n_tris ? pad : 0.f, f2);
+        flat.nodes.swap(f2.nodes); flat.tri_order.swap(f2.tri_order);
+        flat.n_nodes = f2.n_nodes; flat.n_leaves = f2.n_leaves; flat.depth = f2.depth;
+        flat.stack_need = std::max(f2.depth, bvh2_stack_need(br));
+    }
+    if (flat.stack_need + 2 > 64) return fail(c, RT_E_TOO_LARGE, "internal: traversal stack would exceed the LDS budget");
 
     // 3. device records
     std::vector<float> tri48((size_t)n_tris * 12), nrm48((size_t)n_tris * 12), sph((size_t)n_spheres * 4);
@@ -283,6 +305,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     st = rt_scene_stats{};
     st.n_tris = n_tris; st.n_spheres = n_spheres; st.n_lights = n_lights;
     st.n_nodes = flat.n_nodes; st.n_leaves = flat.n_leaves; st.max_depth = flat.depth;
+    c->stack_need = flat.stack_need; c->layout = layout;
     st.node_bytes = 64; st.tri_bytes = 48;
     st.sah_cost = br.sah_cost;
     st.build_ms = (float)(t1 - t0); st.upload_ms = (float)(t2 - t1);

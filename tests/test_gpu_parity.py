@@ -77,7 +77,7 @@ def to_dev(torch, a):
 
 
 # ---- C1: Cornell box, the reference's own scene ------------------------------------------------------
-@pytest.mark.parametrize("mode", [rt.TRAVERSAL_AUTO, rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_AUTO, rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q])
 def test_c1_cornell_512_full_frame_bit_exact(renderer, mode):
     tris, sph, _ = scenes.cornell()
     cam = rt.default_camera(1.0)
@@ -91,7 +91,7 @@ def test_c1_cornell_512_full_frame_bit_exact(renderer, mode):
     assert (got["prim"] != rt.MISS).all()                      # closed box: every primary ray hits
 
 
-@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q])
 def test_kats_on_gpu(renderer, mode):
     tris, sph, _ = scenes.cornell()
     renderer.set_option(rt.OPT_TRAVERSAL, mode)
@@ -103,7 +103,7 @@ def test_kats_on_gpu(renderer, mode):
         assert (float(h["t"]), float(h["u"]), float(h["v"])) == (k["t"], k["u"], k["v"]), name
 
 
-@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q])
 def test_golden_fixtures_on_gpu(renderer, mode):
     renderer.set_option(rt.OPT_TRAVERSAL, mode)
     tris, sph, _ = scenes.cornell()
@@ -182,7 +182,7 @@ def test_spheres_only_and_sphere_tie_rule(renderer):
     tri = np.zeros(1, dtype=rt.TRIANGLE)
     tri[0]["v0"]["position"], tri[0]["v1"]["position"], tri[0]["v2"]["position"] = (-4, -4, 1), (4, -4, 1), (0, 8, 1)
     rays = mk_rays([(0, 0, 3), (0, 0, 0), (5, 5, 5)], [(0, 0, -1), (0, 0, 1), (0, 0, 1)])
-    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH):
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q):
         renderer.set_option(rt.OPT_TRAVERSAL, mode)
         renderer.create_data(None, sph)
         assert_parity(renderer.trace(rays), oracle.trace(oracle.Scene(None, sph), rays), "spheres only")
@@ -203,7 +203,7 @@ def test_intervals_degenerates_and_axis_aligned_rays(renderer):
     rays["tmax"][1] = 6.0           # hit exactly at tmax is rejected
     rays["tmin"][2] = 6.5           # interval beyond the hit
     rays["tmax"][3] = 0.0           # empty interval
-    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH):
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q):
         renderer.set_option(rt.OPT_TRAVERSAL, mode)
         renderer.create_data(tris, sph)
         assert_parity(renderer.trace(rays), oracle.trace(sc, rays), f"edge rays mode {mode}")
@@ -235,7 +235,7 @@ def test_soup_bvh_and_brute_vs_oracle(renderer, n_tris, half, n_rays, leaf):
     ref = oracle.trace(oracle.Scene(st), rays)
     assert (ref["prim"] != rt.MISS).any()
     renderer.set_option(rt.OPT_MAX_LEAF, leaf)
-    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH):
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q):
         renderer.set_option(rt.OPT_TRAVERSAL, mode)
         stats = renderer.create_data(st)
         assert stats["max_depth"] <= 31
@@ -318,7 +318,7 @@ def test_full_frame_bvh_equals_reference_loop_on_gpu(renderer, torch_dev):
     w, h = 1280, 720
     n = w * h
     out = {}
-    for mode in (rt.TRAVERSAL_BVH, rt.TRAVERSAL_BRUTE):
+    for mode in (rt.TRAVERSAL_BVH4Q, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BRUTE):
         renderer.set_option(rt.OPT_TRAVERSAL, mode)
         renderer.create_data(tris, sph)
         rays, hits, brays, bhits = dev_buf(torch, n, 32), dev_buf(torch, n, 16), dev_buf(torch, n, 32), dev_buf(torch, n, 16)
@@ -328,8 +328,9 @@ def test_full_frame_bvh_equals_reference_loop_on_gpu(renderer, torch_dev):
         renderer.trace_dev(brays, n, bhits, stream=s)
         torch.cuda.synchronize()
         out[mode] = (to_np(hits, rt.HIT).copy(), to_np(bhits, rt.HIT).copy())
-    assert_parity(out[rt.TRAVERSAL_BVH][0], out[rt.TRAVERSAL_BRUTE][0], "full-frame primary: BVH vs reference loop")
-    assert_parity(out[rt.TRAVERSAL_BVH][1], out[rt.TRAVERSAL_BRUTE][1], "full-frame bounce: BVH vs reference loop")
+    for m in (rt.TRAVERSAL_BVH4Q, rt.TRAVERSAL_BVH2):
+        assert_parity(out[m][0], out[rt.TRAVERSAL_BRUTE][0], f"full-frame primary: layout {m} vs reference loop")
+        assert_parity(out[m][1], out[rt.TRAVERSAL_BRUTE][1], f"full-frame bounce: layout {m} vs reference loop")
 
 
 def test_counters_and_idempotence(renderer, torch_dev):
@@ -349,7 +350,7 @@ def test_counters_and_idempotence(renderer, torch_dev):
     torch.cuda.synchronize()
     c = renderer.counters()
     assert to_np(d_hits, rt.HIT).tobytes() == first.tobytes()            # instrumented kernel, same answers
-    assert c["rays"] == len(rays) and c["box_tests"] == 2 * c["nodes"] and c["tri_tests"] > 0
+    assert c["rays"] == len(rays) and 2 * c["nodes"] <= c["box_tests"] <= 4 * c["nodes"] and c["tri_tests"] > 0
     assert c["nodes"] / c["rays"] < 200
 
 
