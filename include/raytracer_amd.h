@@ -153,6 +153,24 @@ int  rt_shadow_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_
 int  rt_bounce_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
                    uint32_t key0, uint32_t seed, rt_ray* d_rays_out, void* stream);
 
+/* ---- shading + path loop (frag.glsl:205-263, :303-360) ---------------------------- */
+/* throughput = (1,1,1), radiance = 0 for n paths (frag.glsl:304, :308); 4 floats per path each. */
+int  rt_path_init_dev(rt_ctx* ctx, int slot, uint64_t n, float* d_throughput4, float* d_radiance4, void* stream);
+/* One iteration of main()'s bounce loop (frag.glsl:310-354) for n path segments: emission (:313), every
+ * light's shadow test + Cook-Torrance term (:319-338), the next cosine-weighted ray (:340-343) and the
+ * throughput update (:345-350).  A miss ends the path: the output ray is dead (tmax 0).
+ * RNG key of element i = key0 + i. */
+int  rt_shade_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
+                  uint32_t seed, float* d_throughput4, float* d_radiance4, rt_ray* d_rays_out, void* stream);
+/* frag.glsl:357-359: per pixel, sum of its spp radiance records / spp, then pow(c, 1/2.6) -> RGBA8 (a = 255).
+ * d_linear4 (4 floats per pixel, pre-gamma) and d_rgba8 may each be NULL, not both. */
+int  rt_resolve_dev(rt_ctx* ctx, int slot, const float* d_radiance4, uint64_t n_pixels, uint32_t spp,
+                    float* d_linear4, uint8_t* d_rgba8, void* stream);
+/* The whole of frag.glsl:main for a w x h frame: spp jittered samples per pixel (the reference: 10), `bounces`
+ * path segments (the reference: 8), lights as uploaded.  host_rgba8[(y*w+x)*4 ..], row 0 = top.  The RNG is the
+ * seeded hash of DESIGN.md (frag.glsl:13-15 is parity-unpinned), sample s of pixel p uses key (p*spp+s). */
+int  rt_render(rt_ctx* ctx, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* host_rgba8);
+
 int  rt_counters_get(rt_ctx* ctx, int slot, rt_counters* out, int reset);
 int  rt_sync(rt_ctx* ctx, int slot);
 

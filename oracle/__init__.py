@@ -55,6 +55,10 @@ def lib():
             "orc_hemisphere_libm": (None, [FP, F, F, FP]),
             "orc_rand": (F, [U32, U32, U32]),
             "orc_num_threads": (C.c_int, []),
+            "orc_brdf": (None, [FP, FP, FP, FP, FP]),
+            "orc_shade": (None, [P, P, P, U64, U32, U32, P, P, P]),
+            "orc_resolve": (None, [P, U64, U32, P, P]),
+            "orc_render": (None, [P, P, U32, U32, U32, U32, U32, P, P]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -128,6 +132,42 @@ def bounce(scene, rays, hits, seed=0):
     out = np.empty(len(rays), dtype=RAY)
     if len(rays):
         lib().orc_bounce(scene.ref(), _p(rays), _p(hits), len(rays), seed, _p(out))
+    return out
+
+
+def shade(scene, rays, hits, throughput, radiance, key0=0, seed=0):
+    """One bounce of frag.glsl:310-354; throughput/radiance ([n,4] float32) are updated in place."""
+    rays = np.ascontiguousarray(rays, dtype=RAY)
+    hits = np.ascontiguousarray(hits, dtype=HIT)
+    assert throughput.dtype == np.float32 and radiance.dtype == np.float32 and throughput.flags.c_contiguous
+    out = np.empty(len(rays), dtype=RAY)
+    if len(rays):
+        lib().orc_shade(scene.ref(), _p(rays), _p(hits), len(rays), key0, seed, _p(throughput), _p(radiance), _p(out))
+    return out
+
+
+def resolve(radiance, n_pixels, spp):
+    lin = np.empty((n_pixels, 4), dtype=np.float32)
+    rgba = np.empty((n_pixels, 4), dtype=np.uint8)
+    lib().orc_resolve(_p(radiance), n_pixels, spp, _p(lin), _p(rgba))
+    return lin, rgba
+
+
+def render(scene, camera_ubo, w, h, spp, bounces, seed):
+    cam = np.ascontiguousarray(camera_ubo)
+    lin = np.empty((h, w, 4), dtype=np.float32)
+    rgba = np.empty((h, w, 4), dtype=np.uint8)
+    lib().orc_render(scene.ref(), C.c_void_p(cam.ctypes.data), w, h, spp, bounces, seed, _p(lin.reshape(-1)), _p(rgba.reshape(-1)))
+    return lin, rgba
+
+
+def brdf(material12, n, v, l):
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    out = np.zeros(3, dtype=np.float32)
+    m, nn, vv, ll = (np.ascontiguousarray(x, dtype=np.float32) for x in (material12, n, v, l))
+    lib().orc_brdf(m.ctypes.data_as(C.POINTER(C.c_float)), nn.ctypes.data_as(C.POINTER(C.c_float)),
+                   vv.ctypes.data_as(C.POINTER(C.c_float)), ll.ctypes.data_as(C.POINTER(C.c_float)),
+                   out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
 
 

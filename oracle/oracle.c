@@ -15,6 +15,7 @@
 #include "oracle.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -315,6 +316,152 @@ void orc_bounce(const orc_scene* s, const orc_ray* rays, const orc_hit* hits, ui
         }
         out[i] = br;
     }
+}
+
+/* ---- frag.glsl:205-263 Cook-Torrance ------------------------------------------------------------
+ * pow(x, 5.0) is evaluated as ((x*x)*(x*x))*x (GLSL leaves pow precision open); PI is the fp32 value
+ * of the shader's literal (:5); mix(a, b, t) = a*(1-t) + b*t as GLSL defines it. */
+#define ORC_PI 3.14159274f
+static inline float max0(float x) { return x > 0.0f ? x : 0.0f; }          /* max(x, 0.0) */
+static inline float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
+static inline float geometry_schlick_ggx(float ndv, float roughness) {     /* :221-228 */
+    float r = roughness + 1.0f;
+    float k = (r * r) / 8.0f;
+    float denom = fmaf(ndv, 1.0f - k, k);
+    return ndv / denom;
+}
+static v3 brdf(const float* m, v3 N, v3 Vv, v3 L) {
+    v3 albedo = V(m[0], m[1], m[2]);
+    float roughness = m[8], metallic = m[9];
+    v3 H = normalize(V(Vv.x + L.x, Vv.y + L.y, Vv.z + L.z));               /* :240 */
+    float NdotL = max0(dot(N, L)), NdotV = max0(dot(N, Vv));               /* :242-243 */
+    float NdotH = max0(dot(N, H)), VdotH = max0(dot(Vv, H));               /* :244-245 */
+    float om = 1.0f - metallic;
+    v3 F0 = V(fmaf(albedo.x, metallic, 0.04f * om), fmaf(albedo.y, metallic, 0.04f * om),
+              fmaf(albedo.z, metallic, 0.04f * om));                       /* :247 mix */
+    float p5 = pow5(1.0f - VdotH);                                         /* :206 */
+    v3 F = V(fmaf(1.0f - F0.x, p5, F0.x), fmaf(1.0f - F0.y, p5, F0.y), fmaf(1.0f - F0.z, p5, F0.z));
+    float a = roughness * roughness, a2 = a * a;                           /* :210-211 */
+    float dd = fmaf(NdotH * NdotH, a2 - 1.0f, 1.0f);                       /* :215 */
+    float D = a2 / ((ORC_PI * dd) * dd);                                   /* :216-218 */
+    float G = geometry_schlick_ggx(NdotL, roughness) * geometry_schlick_ggx(NdotV, roughness);  /* :230-237 */
+    float denominator = fmaf(4.0f * NdotV, NdotL, 0.001f);                 /* :254 */
+    float kd = 1.0f - metallic;                                            /* :258 */
+    v3 out;
+    {   float num = (D * F.x) * G; float spec = num / denominator;         /* :253-255 */
+        float kD = (1.0f - F.x) * kd; out.x = (kD * albedo.x) / ORC_PI + spec; }   /* :257-262 */
+    {   float num = (D * F.y) * G; float spec = num / denominator;
+        float kD = (1.0f - F.y) * kd; out.y = (kD * albedo.y) / ORC_PI + spec; }
+    {   float num = (D * F.z) * G; float spec = num / denominator;
+        float kD = (1.0f - F.z) * kd; out.z = (kD * albedo.z) / ORC_PI + spec; }
+    return out;
+}
+void orc_brdf(const float m[12], const float n[3], const float v[3], const float l[3], float out[3]) {
+    v3 r = brdf(m, V(n[0], n[1], n[2]), V(v[0], v[1], v[2]), V(l[0], l[1], l[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+static const float* hit_material(const orc_scene* s, uint32_t prim) {
+    if (prim & ORC_SPHERE_BIT)
+        return (const float*)((const char*)s->spheres + (size_t)(prim & ~ORC_SPHERE_BIT) * s->sphere_stride + SPH_MAT);
+    return (const float*)((const char*)s->tris + (size_t)prim * s->tri_stride + TRI_MAT);
+}
+
+/* frag.glsl:310-354, one bounce for a batch */
+void orc_shade(const orc_scene* s, const orc_ray* rays, const orc_hit* hits, uint64_t n, uint32_t key0,
+               uint32_t seed, float* thr, float* rad, orc_ray* out) {
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        float p[3], nn[3];
+        orc_ray br; memset(&br, 0, sizeof br);
+        if (!(rays[i].tmax > rays[i].tmin) || !orc_hit_point(s, &rays[i], &hits[i], p, nn)) { out[i] = br; continue; }   /* :351-353 */
+        const float* m = hit_material(s, hits[i].prim);
+        v3 T = V(thr[4 * i], thr[4 * i + 1], thr[4 * i + 2]);
+        v3 C = V(rad[4 * i], rad[4 * i + 1], rad[4 * i + 2]);
+        float es = m[7];
+        C = V(fmaf(T.x * m[4], es, C.x), fmaf(T.y * m[5], es, C.y), fmaf(T.z * m[6], es, C.z));      /* :313 */
+        v3 P = V(p[0], p[1], p[2]), N = V(nn[0], nn[1], nn[2]);                                      /* :315 */
+        v3 Vv = normalize(V(-rays[i].dx, -rays[i].dy, -rays[i].dz));                                 /* :316 */
+        for (uint32_t li = 0; li < s->n_lights; ++li) {                                              /* :319 */
+            const char* lp = (const char*)s->lights + (size_t)li * s->light_stride;
+            v3 lpos = ld3(lp, 0), lcol = ld3(lp, 16);
+            float inten = ldf(lp, 28);
+            v3 toL = sub(lpos, P);
+            v3 L = normalize(toL);                                                                   /* :321 */
+            float distance = sqrtf(dot(toL, toL));                                                   /* :322 */
+            float attenuation = 1.0f / (distance * distance);                                        /* :323 */
+            v3 so = madd(0.001f, N, P);                                                              /* :326 */
+            orc_ray sr = { so.x, so.y, so.z, 0.0f, L.x, L.y, L.z, 1e20f };
+            orc_hit sh;
+            orc_trace_one(s, &sr, &sh);
+            int lit = 1;
+            if (sh.prim != ORC_MISS) {
+                v3 dl = sub(madd(sh.t, L, so), P);
+                lit = sqrtf(dot(dl, dl)) > distance;                                                 /* :330 */
+            }
+            if (lit) {
+                v3 B = brdf(m, N, Vv, L);                                                            /* :331 */
+                float NdotL = max0(dot(N, L));                                                       /* :333 */
+                float ia = inten * attenuation;
+                v3 radiance = V(lcol.x * ia, lcol.y * ia, lcol.z * ia);                              /* :335 */
+                C = V(fmaf((T.x * B.x) * radiance.x, NdotL, C.x), fmaf((T.y * B.y) * radiance.y, NdotL, C.y),
+                      fmaf((T.z * B.z) * radiance.z, NdotL, C.z));                                   /* :336 */
+            }
+        }
+        uint32_t key = key0 + (uint32_t)i;
+        float xi1 = orc_rand(key, 2u, seed), xi2 = orc_rand(key, 3u, seed);
+        v3 dir = hemisphere(N, xi1, xi2);                                                            /* :340 */
+        v3 o = madd(0.001f, N, P);                                                                   /* :342 */
+        br.ox = o.x; br.oy = o.y; br.oz = o.z; br.tmin = 0.0f;
+        br.dx = dir.x; br.dy = dir.y; br.dz = dir.z; br.tmax = 1e20f;
+        float NdotR = max0(dot(N, dir));                                                             /* :345 */
+        float pdf = NdotR / ORC_PI;                                                                  /* :346 */
+        v3 B = brdf(m, N, Vv, dir);                                                                  /* :348 */
+        T = V(T.x * ((B.x * NdotR) / pdf), T.y * ((B.y * NdotR) / pdf), T.z * ((B.z * NdotR) / pdf));   /* :350 */
+        thr[4 * i] = T.x; thr[4 * i + 1] = T.y; thr[4 * i + 2] = T.z;
+        rad[4 * i] = C.x; rad[4 * i + 1] = C.y; rad[4 * i + 2] = C.z;
+        out[i] = br;
+    }
+}
+
+/* frag.glsl:357-359 */
+void orc_resolve(const float* rad, uint64_t n_pixels, uint32_t spp, float* lin, uint8_t* rgba) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < (int64_t)n_pixels; ++p) {
+        float c[3] = { 0.0f, 0.0f, 0.0f };
+        for (uint32_t k = 0; k < spp; ++k)
+            for (int a = 0; a < 3; ++a) c[a] += rad[4 * ((size_t)p * spp + k) + a];      /* color += ... over samples */
+        for (int a = 0; a < 3; ++a) c[a] = c[a] / (float)spp;                             /* :357 */
+        if (lin) { lin[4 * p] = c[0]; lin[4 * p + 1] = c[1]; lin[4 * p + 2] = c[2]; lin[4 * p + 3] = 1.0f; }
+        if (rgba) {
+            for (int a = 0; a < 3; ++a) {
+                float g = powf(c[a], 1.0f / 2.6f);                                        /* :358 */
+                g = g < 0.0f ? 0.0f : (g > 1.0f ? 1.0f : g);
+                if (!(g == g)) g = 0.0f;
+                rgba[4 * p + a] = (uint8_t)(g * 255.0f + 0.5f);
+            }
+            rgba[4 * p + 3] = 255;                                                        /* :359 alpha 1.0 */
+        }
+    }
+}
+
+void orc_render(const orc_scene* s, const void* cam, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
+                uint32_t seed, float* lin, uint8_t* rgba) {
+    size_t n = (size_t)w * h * spp;
+    orc_ray* rays = (orc_ray*)malloc(n * sizeof(orc_ray));
+    orc_ray* next = (orc_ray*)malloc(n * sizeof(orc_ray));
+    orc_hit* hits = (orc_hit*)malloc(n * sizeof(orc_hit));
+    float* thr = (float*)malloc(n * 16);
+    float* rad = (float*)calloc(n, 16);
+    for (size_t i = 0; i < n; ++i) { thr[4 * i] = thr[4 * i + 1] = thr[4 * i + 2] = 1.0f; thr[4 * i + 3] = 0.0f; }   /* :308 */
+    orc_primary_rays(cam, w, h, spp, seed, 1, rays);                                      /* :307 */
+    for (uint32_t b = 0; b < bounces; ++b) {                                              /* :310 */
+        orc_trace(s, rays, n, hits);                                                      /* :312 */
+        orc_shade(s, rays, hits, n, 0u, seed + 1u + b, thr, rad, next);
+        orc_ray* t = rays; rays = next; next = t;
+    }
+    orc_resolve(rad, (uint64_t)w * h, spp, lin, rgba);
+    free(rays); free(next); free(hits); free(thr); free(rad);
 }
 
 int orc_num_threads(void) {

@@ -202,6 +202,23 @@ class Renderer:
         self._check(self._lib.rt_bounce_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, key0, seed, _ptr(out_rays),
                                             _stream_ptr(stream)))
 
+    def path_init_dev(self, n, throughput, radiance, slot=0, stream=None):
+        self._check(self._lib.rt_path_init_dev(self._ctx, slot, n, _ptr(throughput), _ptr(radiance), _stream_ptr(stream)))
+
+    def shade_dev(self, rays, hits, n, throughput, radiance, out_rays, key0=0, seed=0, slot=0, stream=None):
+        self._check(self._lib.rt_shade_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, key0, seed, _ptr(throughput),
+                                           _ptr(radiance), _ptr(out_rays), _stream_ptr(stream)))
+
+    def resolve_dev(self, radiance, n_pixels, spp, linear=None, rgba8=None, slot=0, stream=None):
+        self._check(self._lib.rt_resolve_dev(self._ctx, slot, _ptr(radiance), n_pixels, spp, _ptr(linear), _ptr(rgba8),
+                                             _stream_ptr(stream)))
+
+    def render(self, w, h, spp=10, bounces=8, seed=1):
+        """frag.glsl:main for a whole frame (defaults: the shader's SAMPLES / BOUNCES) -> (h, w, 4) uint8."""
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check(self._lib.rt_render(self._ctx, w, h, spp, bounces, seed, _ptr(out)))
+        return out
+
     def counters(self, slot=0, reset=True):
         c = rt_counters()
         self._check(self._lib.rt_counters_get(self._ctx, slot, C.byref(c), int(reset)))

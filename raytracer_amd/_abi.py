@@ -46,6 +46,10 @@ SYMBOLS = [
     ("rt_occluded_dev", _I, [_P, _I, _P, _U64, _P, _P]),
     ("rt_shadow_dev", _I, [_P, _I, _P, _P, _U64, C.POINTER(C.c_float), _P, _P, _P]),
     ("rt_bounce_dev", _I, [_P, _I, _P, _P, _U64, _U32, _U32, _P, _P]),
+    ("rt_path_init_dev", _I, [_P, _I, _U64, _P, _P, _P]),
+    ("rt_shade_dev", _I, [_P, _I, _P, _P, _U64, _U32, _U32, _P, _P, _P, _P]),
+    ("rt_resolve_dev", _I, [_P, _I, _P, _U64, _U32, _P, _P, _P]),
+    ("rt_render", _I, [_P, _U32, _U32, _U32, _U32, _U32, _P]),
     ("rt_counters_get", _I, [_P, _I, C.POINTER(rt_counters), _I]),
     ("rt_sync", _I, [_P, _I]),
     ("rt_gen_cornell_triangles", _U32, [_P, _U32]),

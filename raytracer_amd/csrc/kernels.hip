@@ -584,6 +584,150 @@ __global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __r
     out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
 }
 
+// ---- shading (frag.glsl:205-263) + one bounce of the path loop (:310-354) ------------------------------
+// Same evaluation order as oracle.c: pow(x,5) = ((x*x)*(x*x))*x, mix(a,b,t) = fma(b,t,a*(1-t)), PI = fp32(3.14159265...).
+constexpr float kPi = 3.14159274f;
+__device__ __forceinline__ float max0(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ __forceinline__ float schlick_ggx(float ndv, float roughness) {          // :221-228
+    float r = roughness + 1.0f;
+    float k = (r * r) / 8.0f;
+    return ndv / __fmaf_rn(ndv, 1.0f - k, k);
+}
+struct Mat { f3 albedo, emission; float strength, roughness, metallic; };
+__device__ __forceinline__ Mat load_mat(const DevScene& s, uint32_t id) {
+    const float4* mp = s.materials + (size_t)id * 3;
+    float4 a = mp[0], b = mp[1], c = mp[2];
+    Mat m; m.albedo = mk(a.x, a.y, a.z); m.strength = a.w; m.emission = mk(b.x, b.y, b.z); m.roughness = b.w; m.metallic = c.x;
+    return m;
+}
+__device__ __forceinline__ f3 brdf(const Mat& m, f3 N, f3 V, f3 L) {               // :239-263
+    f3 H = norm3(mk(V.x + L.x, V.y + L.y, V.z + L.z));
+    float NdotL = max0(dot3(N, L)), NdotV = max0(dot3(N, V)), NdotH = max0(dot3(N, H)), VdotH = max0(dot3(V, H));
+    float om = 1.0f - m.metallic;
+    f3 F0 = mk(__fmaf_rn(m.albedo.x, m.metallic, 0.04f * om), __fmaf_rn(m.albedo.y, m.metallic, 0.04f * om),
+               __fmaf_rn(m.albedo.z, m.metallic, 0.04f * om));
+    float x = 1.0f - VdotH, x2 = x * x, p5 = (x2 * x2) * x;
+    f3 F = mk(__fmaf_rn(1.0f - F0.x, p5, F0.x), __fmaf_rn(1.0f - F0.y, p5, F0.y), __fmaf_rn(1.0f - F0.z, p5, F0.z));
+    float a = m.roughness * m.roughness, a2 = a * a;
+    float dd = __fmaf_rn(NdotH * NdotH, a2 - 1.0f, 1.0f);
+    float D = a2 / ((kPi * dd) * dd);
+    float G = schlick_ggx(NdotL, m.roughness) * schlick_ggx(NdotV, m.roughness);
+    float denominator = __fmaf_rn(4.0f * NdotV, NdotL, 0.001f);
+    float kd = 1.0f - m.metallic;
+    f3 out;
+    out.x = (((1.0f - F.x) * kd) * m.albedo.x) / kPi + ((D * F.x) * G) / denominator;
+    out.y = (((1.0f - F.y) * kd) * m.albedo.y) / kPi + ((D * F.y) * G) / denominator;
+    out.z = (((1.0f - F.z) * kd) * m.albedo.z) / kPi + ((D * F.z) * G) / denominator;
+    return out;
+}
+
+__device__ __forceinline__ f3 hemisphere(f3 N, float xi1, float xi2) {             // :185-203
+    float ct = sqrtf(1.0f - xi1), st = sqrtf(xi1);
+    float sphi, cphi;
+    sincos_2pi(xi2, sphi, cphi);
+    float xs = st * cphi, ys = ct, zs = st * sphi;
+    f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);
+    f3 tX = norm3(cross3(up, N));
+    f3 tY = cross3(N, tX);
+    f3 dir = mk(__fmaf_rn(N.x, ys, __fmaf_rn(tY.x, zs, tX.x * xs)), __fmaf_rn(N.y, ys, __fmaf_rn(tY.y, zs, tX.y * xs)),
+                __fmaf_rn(N.z, ys, __fmaf_rn(tY.z, zs, tX.z * xs)));
+    return norm3(dir);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
+                                                  const float4* __restrict__ hits, uint64_t n, uint32_t key0,
+                                                  uint32_t seed, float4* __restrict__ thr, float4* __restrict__ rad,
+                                                  float4* __restrict__ out) {
+    extern __shared__ int stack[];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* rp = reinterpret_cast<const float4*>(rays + i);
+    float4 r0 = rp[0], r1 = rp[1];
+    float4 hit = hits[i];
+    f3 P, N;
+    f3 d = mk(r1.x, r1.y, r1.z);
+    if (!(r1.w > r0.w) || !hit_point(s, mk(r0.x, r0.y, r0.z), d, hit, P, N)) {     // :351-353 the path ends
+        out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const uint32_t prim = __float_as_uint(hit.w);
+    const uint32_t mid = (prim & RT_SPHERE_BIT) ? s.sphere_mat[prim & ~RT_SPHERE_BIT]
+                                                : __float_as_uint(s.normals[(size_t)prim * 3].w);
+    const Mat m = load_mat(s, mid);
+    float4 t4 = thr[i], c4 = rad[i];
+    f3 T = mk(t4.x, t4.y, t4.z), C = mk(c4.x, c4.y, c4.z);
+    C = mk(__fmaf_rn(T.x * m.emission.x, m.strength, C.x), __fmaf_rn(T.y * m.emission.y, m.strength, C.y),
+           __fmaf_rn(T.z * m.emission.z, m.strength, C.z));                         // :313
+    f3 V = norm3(mk(-d.x, -d.y, -d.z));                                             // :316
+    for (uint32_t li = 0; li < s.n_lights; ++li) {                                  // :319-338
+        float4 l0 = s.lights[2 * li], l1 = s.lights[2 * li + 1];
+        f3 toL = sub3(mk(l0.x, l0.y, l0.z), P);
+        f3 L = norm3(toL);
+        float distance = sqrtf(dot3(toL, toL));
+        float attenuation = 1.0f / (distance * distance);
+        f3 so = madd3(0.001f, N, P);
+        Best b; Counters c = { 0, 0, 0, 0 };
+        const float tmax = 1e20f;
+        trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
+        bool lit = true;
+        if (b.t < tmax) {
+            f3 dl = sub3(madd3(b.t, L, so), P);
+            lit = sqrtf(dot3(dl, dl)) > distance;                                   // :330
+        }
+        if (lit) {
+            f3 B = brdf(m, N, V, L);
+            float NdotL = max0(dot3(N, L));
+            float ia = l0.w * attenuation;
+            C = mk(__fmaf_rn((T.x * B.x) * (l1.x * ia), NdotL, C.x), __fmaf_rn((T.y * B.y) * (l1.y * ia), NdotL, C.y),
+                   __fmaf_rn((T.z * B.z) * (l1.z * ia), NdotL, C.z));                // :335-336
+        }
+    }
+    const uint32_t key = key0 + (uint32_t)i;
+    f3 dir = hemisphere(N, rand01(key, 2u, seed), rand01(key, 3u, seed));           // :340
+    f3 o = madd3(0.001f, N, P);                                                     // :342
+    float NdotR = max0(dot3(N, dir));                                               // :345
+    float pdf = NdotR / kPi;                                                        // :346
+    f3 B = brdf(m, N, V, dir);                                                      // :348
+    T = mk(T.x * ((B.x * NdotR) / pdf), T.y * ((B.y * NdotR) / pdf), T.z * ((B.z * NdotR) / pdf));   // :350
+    thr[i] = make_float4(T.x, T.y, T.z, 0.0f);
+    rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
+    out[2 * i] = make_float4(o.x, o.y, o.z, 0.0f);
+    out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
+}
+
+// frag.glsl:357-359.  powf is the device libm's: the gamma step is compared with a tolerance, the linear
+// average is bit-exact.
+__global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ rad, uint64_t n_pixels, uint32_t spp,
+                                                    float4* __restrict__ lin, uint32_t* __restrict__ rgba) {
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_pixels) return;
+    float c[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t k = 0; k < spp; ++k) {
+        float4 r = rad[p * spp + k];
+        c[0] += r.x; c[1] += r.y; c[2] += r.z;
+    }
+    const float fs = (float)spp;
+    c[0] = c[0] / fs; c[1] = c[1] / fs; c[2] = c[2] / fs;
+    if (lin) lin[p] = make_float4(c[0], c[1], c[2], 1.0f);
+    if (rgba) {
+        uint32_t px = 0xff000000u;
+        #pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float g = powf(c[a], 1.0f / 2.6f);
+            g = g < 0.0f ? 0.0f : (g > 1.0f ? 1.0f : g);
+            if (!(g == g)) g = 0.0f;
+            px |= (uint32_t)(g * 255.0f + 0.5f) << (8 * a);
+        }
+        rgba[p] = px;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill(float4* __restrict__ d, uint64_t n, float4 v) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+
 // LDS for the per-lane stacks: sentinel + one entry per BVH level (+1 spare), [entry][thread]
 inline size_t stack_bytes(const DevScene& s, int mode) {
     return mode != kBrute ? (size_t)(s.stack_depth + 2) * kBlock * sizeof(int) : 0;
@@ -649,6 +793,34 @@ hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, cons
 #define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shadow<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit)
     if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH_M
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                        uint32_t key0, uint32_t seed, float4* d_throughput, float4* d_radiance, rt_ray* d_out,
+                        hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    dim3 g(grid_for(n)), b(kBlock);
+    const float4* hits = reinterpret_cast<const float4*>(d_hits);
+    float4* out = reinterpret_cast<float4*>(d_out);
+    // the traversal inside k_shade only runs when the scene has lights
+    const int m = s.n_lights ? mode : kBrute;
+#define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shade<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, seed, d_throughput, d_radiance, out)
+    if (m == kBrute) RT_LAUNCH_M(kBrute); else if (m == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
+#undef RT_LAUNCH_M
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t spp, float4* d_linear, uint32_t* d_rgba8,
+                          hipStream_t st) {
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_pixels)), dim3(kBlock), 0, st, d_radiance, n_pixels, spp, d_linear, d_rgba8);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, d, n, make_float4(x, y, z, w));
     return hipGetLastError();
 }
 

@@ -12,7 +12,10 @@ struct DevScene {
     const float4* tris;      // 3 x float4 per triangle in leaf order: (v0, bits id) (e1, 0) (e2, 0)
     const float4* normals;   // 3 x float4 per triangle in ORIGINAL order: n0, n1, n2
     const float4* spheres;   // (centre, radius)
-    uint32_t n_nodes, n_tris, n_spheres, stack_depth;
+    const float4* materials; // 3 x float4 per distinct material: (albedo, strength) (emission, roughness) (metallic,0,0,0)
+    const uint32_t* sphere_mat;  // material id per sphere; triangles keep theirs in normals[3*i].w
+    const float4* lights;    // 2 x float4 per light: (position, intensity) (colour, 0)
+    uint32_t n_nodes, n_tris, n_spheres, stack_depth, n_lights;
 };
 
 // Camera constants precomputed on the host by rt_set_camera (frag.glsl:106-110: tan of the half fov
@@ -40,6 +43,15 @@ hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, cons
 
 hipError_t launch_bounce(const DevScene& s, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
                          uint32_t seed, rt_ray* d_out, hipStream_t st);
+
+// frag.glsl:310-354, one bounce of the path loop for a batch (emission, direct light, next ray, throughput)
+hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                        uint32_t key0, uint32_t seed, float4* d_throughput, float4* d_radiance, rt_ray* d_out,
+                        hipStream_t st);
+// frag.glsl:357-359: average over spp, gamma 1/2.6, RGBA8 (+ optional linear float4)
+hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t spp, float4* d_linear, uint32_t* d_rgba8,
+                          hipStream_t st);
+hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
 
 constexpr int kStackDepth = 32;   // per-lane traversal stack entries held in LDS
 constexpr int kNumCounters = 8;   // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves

@@ -14,7 +14,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <array>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,6 +34,11 @@ struct Replica {
     float4* d_tris = nullptr;
     float4* d_normals = nullptr;
     float4* d_spheres = nullptr;
+    float4* d_materials = nullptr;
+    float4* d_sphere_mat = nullptr;   // uint32 ids, allocated through the float4 helper
+    float4* d_lights = nullptr;
+    // scratch for rt_render
+    void* d_render = nullptr; size_t render_cap = 0;
     unsigned long long* d_counters = nullptr;
     // scratch for host-pointer entry points
     void* d_rays = nullptr;  size_t rays_cap = 0;
@@ -71,6 +78,8 @@ struct rt_ctx {
     DevScene dev_scene(const Replica& r) const {
         DevScene s;
         s.nodes = r.d_nodes; s.tris = r.d_tris; s.normals = r.d_normals; s.spheres = r.d_spheres;
+        s.materials = r.d_materials; s.sphere_mat = reinterpret_cast<const uint32_t*>(r.d_sphere_mat); s.lights = r.d_lights;
+        s.n_lights = stats.n_lights;
         s.n_nodes = stats.n_nodes; s.n_tris = stats.n_tris; s.n_spheres = stats.n_spheres;
         s.stack_depth = stack_need;
         return s;
@@ -98,7 +107,10 @@ void free_scene(Replica& r) {
     if (r.d_tris) (void)hipFree(r.d_tris);
     if (r.d_normals) (void)hipFree(r.d_normals);
     if (r.d_spheres) (void)hipFree(r.d_spheres);
-    r.d_nodes = r.d_tris = r.d_normals = r.d_spheres = nullptr;
+    if (r.d_materials) (void)hipFree(r.d_materials);
+    if (r.d_sphere_mat) (void)hipFree(r.d_sphere_mat);
+    if (r.d_lights) (void)hipFree(r.d_lights);
+    r.d_nodes = r.d_tris = r.d_normals = r.d_spheres = r.d_materials = r.d_sphere_mat = r.d_lights = nullptr;
 }
 
 bool valid_slot(const rt_ctx* c, int slot) { return c && slot >= 0 && slot < (int)c->reps.size(); }
@@ -170,6 +182,7 @@ void rt_destroy(rt_ctx* c) {
         if (r.d_counters) (void)hipFree(r.d_counters);
         if (r.d_rays) (void)hipFree(r.d_rays);
         if (r.d_out) (void)hipFree(r.d_out);
+        if (r.d_render) (void)hipFree(r.d_render);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     delete c;
@@ -271,10 +284,40 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
         o[4] = p1[0] - p0[0]; o[5] = p1[1] - p0[1]; o[6] = p1[2] - p0[2]; o[7] = 0.f;
         o[8] = p2[0] - p0[0]; o[9] = p2[1] - p0[1]; o[10] = p2[2] - p0[2]; o[11] = 0.f;
     }
+    // distinct materials (src/math/Material.h:6-11, 9 floats used) -> table; ids ride in normals[3*i].w / sphere_mat
+    std::vector<float> mats;                       // 12 floats per material: (albedo, strength) (emission, roughness) (metallic,0,0,0)
+    std::map<std::array<uint32_t, 9>, uint32_t> mat_ids;
+    auto material_id = [&](const char* m48) -> uint32_t {
+        float f[10];
+        std::memcpy(f, m48, 40);                   // albedo@0, emission@16, strength@28, roughness@32, metallic@36
+        std::array<uint32_t, 9> key;
+        const float vals[9] = { f[0], f[1], f[2], f[4], f[5], f[6], f[7], f[8], f[9] };
+        std::memcpy(key.data(), vals, 36);
+        auto it = mat_ids.find(key);
+        if (it != mat_ids.end()) return it->second;
+        const uint32_t id = (uint32_t)mat_ids.size();
+        mat_ids.emplace(key, id);
+        const float rec[12] = { f[0], f[1], f[2], f[7], f[4], f[5], f[6], f[8], f[9], 0.f, 0.f, 0.f };
+        mats.insert(mats.end(), rec, rec + 12);
+        return id;
+    };
     for (uint32_t i = 0; i < n_tris; ++i) {
         const char* t = tb + (size_t)i * tri_stride;
         float* o = &nrm48[(size_t)i * 12];
         for (int v = 0; v < 3; ++v) { std::memcpy(o + 4 * v, t + 16 + 32 * v, 12); o[4 * v + 3] = 0.f; }
+        const uint32_t id = material_id(t + 96);
+        std::memcpy(&o[3], &id, 4);
+    }
+    std::vector<float> sphere_mat((size_t)n_spheres), lights8((size_t)n_lights * 8);
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        const uint32_t id = material_id(static_cast<const char*>(spheres) + (size_t)i * sphere_stride + 16);
+        std::memcpy(&sphere_mat[i], &id, 4);
+    }
+    for (uint32_t i = 0; i < n_lights; ++i) {      // src/math/Light.h:6-10: position@0, colour@16, intensity@28
+        const char* l = static_cast<const char*>(lights) + (size_t)i * light_stride;
+        float* o = &lights8[(size_t)i * 8];
+        std::memcpy(o, l, 12); std::memcpy(o + 3, l + 28, 4);
+        std::memcpy(o + 4, l + 16, 12); o[7] = 0.f;
     }
     const char* sb = static_cast<const char*>(spheres);
     for (uint32_t i = 0; i < n_spheres; ++i) std::memcpy(&sph[(size_t)i * 4], sb + (size_t)i * sphere_stride, 16);
@@ -298,6 +341,9 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
         RT_HIP(c, up(&r.d_tris, tri48));
         RT_HIP(c, up(&r.d_normals, nrm48));
         RT_HIP(c, up(&r.d_spheres, sph));
+        RT_HIP(c, up(&r.d_materials, mats));
+        RT_HIP(c, up(&r.d_sphere_mat, sphere_mat));
+        RT_HIP(c, up(&r.d_lights, lights8));
     }
     const double t2 = now_ms();
 
@@ -416,6 +462,92 @@ int rt_bounce_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_bounce(c->dev_scene(r), d_rays, d_hits, n, key0, seed, d_out, st));
     return RT_OK;
+}
+
+int rt_shade_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
+                 uint32_t seed, float* d_throughput4, float* d_radiance4, rt_ray* d_out, void* stream) {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (n && (!d_rays || !d_hits || !d_throughput4 || !d_radiance4 || !d_out)) return fail(c, RT_E_INVALID, "shade: null device pointer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    RT_HIP(c, launch_shade(c->dev_scene(r), c->mode(), d_rays, d_hits, n, key0, seed, reinterpret_cast<float4*>(d_throughput4),
+                           reinterpret_cast<float4*>(d_radiance4), d_out, (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_path_init_dev(rt_ctx* c, int slot, uint64_t n, float* d_throughput4, float* d_radiance4, void* stream) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
+    if (n && (!d_throughput4 || !d_radiance4)) return fail(c, RT_E_INVALID, "path_init: null device pointer");
+    RT_HIP(c, hipSetDevice(c->reps[slot].device));
+    RT_HIP(c, launch_fill(reinterpret_cast<float4*>(d_throughput4), n, 1.f, 1.f, 1.f, 0.f, (hipStream_t)stream));   // frag.glsl:308
+    RT_HIP(c, launch_fill(reinterpret_cast<float4*>(d_radiance4), n, 0.f, 0.f, 0.f, 0.f, (hipStream_t)stream));     // :304
+    return RT_OK;
+}
+
+int rt_resolve_dev(rt_ctx* c, int slot, const float* d_radiance4, uint64_t n_pixels, uint32_t spp, float* d_linear4,
+                   uint8_t* d_rgba8, void* stream) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
+    if (spp == 0 || (n_pixels && (!d_radiance4 || (!d_linear4 && !d_rgba8)))) return fail(c, RT_E_INVALID, "resolve: bad arguments");
+    RT_HIP(c, hipSetDevice(c->reps[slot].device));
+    RT_HIP(c, launch_resolve(reinterpret_cast<const float4*>(d_radiance4), n_pixels, spp, reinterpret_cast<float4*>(d_linear4),
+                             reinterpret_cast<uint32_t*>(d_rgba8), (hipStream_t)stream));
+    return RT_OK;
+}
+
+// frag.glsl:303-360 for a whole frame, as a wavefront pipeline: k_primary, then per bounce k_shade + closest hit.
+int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* host_rgba8) {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!c->has_scene) return fail(c, RT_E_NO_SCENE, "no scene uploaded");
+    if (!c->has_camera) return fail(c, RT_E_NO_CAMERA, "no camera set");
+    if (!host_rgba8 || w == 0 || h == 0 || spp == 0 || bounces == 0) return fail(c, RT_E_INVALID, "render: null output or zero size");
+    if ((uint64_t)w * h * spp > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "render: w*h*spp exceeds 2^32-1");
+    const int ns = (int)c->reps.size();
+    const uint32_t per = ((h + ns - 1) / ns + 7) / 8 * 8;
+    const int mode = c->mode();
+    return for_each_slot(c, [&](int s) -> int {
+        Replica& r = c->reps[s];
+        const uint32_t y0 = std::min<uint64_t>((uint64_t)per * s, h), y1 = std::min<uint64_t>((uint64_t)y0 + per, h);
+        if (y1 <= y0) return RT_OK;
+        const uint32_t rows = y1 - y0;
+        const uint64_t n = (uint64_t)rows * w * spp, npx = (uint64_t)rows * w;
+        // rays A/B (32 B), hits (16 B), throughput (16 B), radiance (16 B) per ray + RGBA8 per pixel
+        const size_t bytes = n * (32 + 32 + 16 + 16 + 16) + npx * 4;
+        RT_HIP_SLOT(r, hipSetDevice(r.device));
+        if (bytes > r.render_cap) {
+            if (r.d_render) (void)hipFree(r.d_render);
+            r.d_render = nullptr; r.render_cap = 0;
+            RT_HIP_SLOT(r, hipMalloc(&r.d_render, bytes));
+            r.render_cap = bytes;
+        }
+        char* base = static_cast<char*>(r.d_render);
+        rt_ray* ra = reinterpret_cast<rt_ray*>(base);
+        rt_ray* rb = reinterpret_cast<rt_ray*>(base + n * 32);
+        rt_hit* hits = reinterpret_cast<rt_hit*>(base + n * 64);
+        float4* thr = reinterpret_cast<float4*>(base + n * 80);
+        float4* rad = reinterpret_cast<float4*>(base + n * 96);
+        uint32_t* rgba = reinterpret_cast<uint32_t*>(base + n * 112);
+        const DevScene ds = c->dev_scene(r);
+        RT_HIP_SLOT(r, launch_fill(thr, n, 1.f, 1.f, 1.f, 0.f, r.stream));
+        RT_HIP_SLOT(r, launch_fill(rad, n, 0.f, 0.f, 0.f, 0.f, r.stream));
+        RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, ra, hits, r.d_counters, r.stream));
+        const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
+        for (uint32_t b = 0; b < bounces; ++b) {
+            RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, seed + 1u + b, thr, rad, rb, r.stream));
+            if (b + 1 < bounces)
+                RT_HIP_SLOT(r, launch_trace(ds, mode, false, false, rb, n, hits, nullptr, r.d_counters, r.stream, c->strip, c->refill));
+            std::swap(ra, rb);
+        }
+        RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));
+        RT_HIP_SLOT(r, hipMemcpyAsync(host_rgba8 + (size_t)y0 * w * 4, rgba, npx * 4, hipMemcpyDeviceToHost, r.stream));
+        RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        return RT_OK;
+    });
 }
 
 int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) {

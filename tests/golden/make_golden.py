@@ -62,6 +62,9 @@ def main():
     np.save(os.path.join(HERE, "c1_cornell_64x64_bounce_rays.npy"), br)
     # jittered 4-spp primary rays
     meta["c1_cornell_rays_32x32x4_seed1_sha256"] = sha(oracle.primary_rays(cam, 32, 32, spp=4, seed=1, jitter=True))
+    # shading + path loop: linear framebuffer of a small Cornell render (lights: none, as shipped)
+    lin, _ = oracle.render(sc, cam, 32, 32, 2, 3, 1)
+    meta["c1_render_32x32_spp2_b3_seed1_linear_sha256"] = sha(lin)
     json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
     print(json.dumps(meta, indent=1))
 

@@ -393,3 +393,72 @@ def test_cpp_headless_harness(tmp_path):
     assert data.startswith(b"P6\n64 48\n255\n") and len(data) == len(b"P6\n64 48\n255\n") + 64 * 48 * 3
     p = subprocess.run([exe, "0", "0", str(out)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 1 and "empty image" in p.stderr          # EXIT_FAILURE + message, as src/main.cpp:8-14
+
+
+# ---- shading + path loop -----------------------------------------------------------------------
+def _lights2():
+    l = np.zeros(2, dtype=rt.LIGHT)
+    l[0]["position"], l[0]["color"], l[0]["intensity"] = (0.0, 0.0, 1.9), (1.0, 1.0, 1.0), 1.0
+    l[1]["position"], l[1]["color"], l[1]["intensity"] = (-1.5, 1.5, 0.6), (1.0, 0.6, 0.3), 0.5
+    return l
+
+
+@pytest.mark.parametrize("with_lights", [False, True])
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q])
+def test_path_loop_stages_bit_exact(renderer, torch_dev, mode, with_lights):
+    """rt_path_init_dev / rt_shade_dev / rt_resolve_dev against orc_shade / orc_resolve: throughput, radiance, next
+    rays and the linear framebuffer are bit-identical; RGBA8 (device powf vs libm powf, frag.glsl:358) within 1 LSB."""
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    lights = _lights2() if with_lights else None
+    cam = rt.default_camera(1.0)
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    renderer.create_data(tris, sph, lights)
+    renderer.update_camera(cam)
+    w, h, spp, bounces, seed = 40, 24, 3, 4, 9
+    n = w * h * spp
+    f = lambda k: torch.empty(n * k, dtype=torch.float32, device="cuda")
+    ra, rb, hits, thr, rad = f(8), f(8), f(4), f(4), f(4)
+    lin = torch.empty(w * h * 4, dtype=torch.float32, device="cuda")
+    rgba = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream()
+    renderer.path_init_dev(n, thr, rad, stream=s)
+    renderer.trace_primary_dev(w, h, hits, ra, spp=spp, seed=seed, jitter=True, stream=s)
+    sc = oracle.Scene(tris, sph, lights)
+    o_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=seed, jitter=True)
+    o_thr = np.ones((n, 4), dtype=np.float32); o_thr[:, 3] = 0
+    o_rad = np.zeros((n, 4), dtype=np.float32)
+    for b in range(bounces):
+        o_hits = oracle.trace(sc, o_rays)
+        torch.cuda.synchronize()
+        assert_parity(to_np(hits, rt.HIT), o_hits, f"bounce {b} hits")
+        renderer.shade_dev(ra, hits, n, thr, rad, rb, key0=0, seed=seed + 1 + b, stream=s)
+        renderer.trace_dev(rb, n, hits, stream=s)
+        o_rays = oracle.shade(sc, o_rays, o_hits, o_thr, o_rad, key0=0, seed=seed + 1 + b)
+        torch.cuda.synchronize()
+        assert to_np(rb, rt.RAY).tobytes() == o_rays.tobytes(), f"bounce {b}: next rays differ"
+        assert thr.cpu().numpy().tobytes() == o_thr.tobytes(), f"bounce {b}: throughput differs"
+        assert rad.cpu().numpy().tobytes() == o_rad.tobytes(), f"bounce {b}: radiance differs"
+        ra, rb = rb, ra
+    renderer.resolve_dev(rad, w * h, spp, lin, rgba, stream=s)
+    torch.cuda.synchronize()
+    o_lin, o_rgba = oracle.resolve(o_rad, w * h, spp)
+    assert lin.cpu().numpy().tobytes() == o_lin.tobytes()
+    assert np.abs(rgba.cpu().numpy().astype(np.int32).reshape(-1, 4) - o_rgba.astype(np.int32)).max() <= 1
+    assert o_rad[:, :3].sum() > 0 and (not with_lights or o_rad[:, :3].mean() > 0.05)
+
+
+def test_rt_render_matches_oracle_frame():
+    """rt_render (host RGBA8, two replicas on the one GPU = the in-process multi-device path) against orc_render;
+    the reference's own SAMPLES/BOUNCES are 10/8 (frag.glsl:3-4), here 4/5 on 96x72 to keep the oracle quick."""
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(96 / 72)
+    _, want = oracle.render(oracle.Scene(tris, sph), cam, 96, 72, 4, 5, 2)
+    for devs in ((0,), (0, 0)):
+        with rt.Renderer(devs) as r:
+            r.create_data(tris, sph)
+            r.update_camera(cam)
+            got = r.render(96, 72, spp=4, bounces=5, seed=2)
+        assert got.shape == (72, 96, 4) and (got[..., 3] == 255).all()
+        assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1, devs
+        assert got[..., :3].mean() > 20                                   # the emissive panel lights the box

@@ -183,3 +183,51 @@ def test_shadow_expression(cornell):
     assert oracle.shadow_lit(sc, pr, ph, (0.0, -10.0, 1.0))[0] == 0
     miss = ray((0, 10, 1), (0, 1, 0))
     assert oracle.shadow_lit(sc, miss, oracle.trace(sc, miss), (0, 0, 1))[0] == 2
+
+
+# ---- shading + path loop (frag.glsl:205-263, :303-360) ------------------------------------------------------
+def test_brdf_known_values():
+    """computeBRDF (frag.glsl:239-263) at N = V = L: NdotX = 1, VdotH = 1 => F = F0, D = 1/(pi a^2), G = 1/(1... )."""
+    m = scenes.material12((0.8, 0.5, 0.2), roughness=0.5, metallic=0.0)
+    got = oracle.brdf(m, (0, 0, 1), (0, 0, 1), (0, 0, 1)).astype(np.float64)
+    a2 = 0.5 ** 4
+    D = a2 / (np.pi * (a2 - 1.0 + 1.0) ** 2)
+    k = (0.5 + 1.0) ** 2 / 8.0
+    G = (1.0 / (1.0 * (1 - k) + k)) ** 2
+    spec = D * 0.04 * G / (4.0 + 0.001)
+    want = (1 - 0.04) * np.array([0.8, 0.5, 0.2]) / np.pi + spec
+    assert np.allclose(got, want, rtol=2e-6)
+    # metallic = 1: no diffuse lobe, F0 = albedo
+    m = scenes.material12((1.0, 0.9, 0.0), roughness=0.1, metallic=1.0)
+    got = oracle.brdf(m, (0, 0, 1), (0.6, 0, 0.8), (-0.6, 0, 0.8)).astype(np.float64)
+    assert got[2] < got[1] < got[0] and got[2] >= 0
+
+
+def test_shade_emission_miss_and_throughput(cornell):
+    tris, sph, sc = cornell
+    rays = np.concatenate([ray((0, 0, 0.5), (0, 0, 1)), ray((0, 10, 1), (0, 1, 0)), ray((0.5, 1, 1), (0, 0, -1))])
+    hits = oracle.trace(sc, rays)
+    assert int(hits[0]["prim"]) in (10, 11) and int(hits[1]["prim"]) == rt.MISS          # light panel / outside
+    thr = np.ones((3, 4), dtype=np.float32); thr[:, 3] = 0
+    rad = np.zeros((3, 4), dtype=np.float32)
+    out = oracle.shade(sc, rays, hits, thr, rad, seed=3)
+    assert np.allclose(rad[0, :3], 0.5) and np.all(rad[1] == 0) and np.all(rad[2] == 0)  # emission 1 x strength 0.5
+    assert out[1]["tmax"] == 0 and np.all(thr[1, :3] == 1)                               # the path ended at the miss
+    # diffuse white floor, cosine sampling: BRDF * cos / pdf = albedo * (1 - F) <= 1
+    assert np.all(thr[2, :3] <= 1.0) and np.all(thr[2, :3] > 0.5)
+    assert np.allclose(out[2]["o"], (0.5, 1.0, 0.001), atol=1e-6) and out[2]["d"][2] > 0
+
+
+def test_render_golden_and_energy(cornell):
+    tris, sph, sc = cornell
+    cam = rt.default_camera(1.0)
+    lin, rgba = oracle.render(sc, cam, 32, 32, 2, 3, 1)
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    assert sha(lin) == meta["c1_render_32x32_spp2_b3_seed1_linear_sha256"]
+    assert not np.isnan(lin).any() and lin[..., :3].max() <= 1.0 and lin[..., :3].mean() > 0.02
+    assert (rgba[..., 3] == 255).all()
+    want = np.clip(np.power(lin[..., :3].astype(np.float64), 1 / 2.6), 0, 1) * 255 + 0.5
+    assert np.abs(rgba[..., :3].astype(np.int64) - want.astype(np.int64)).max() <= 1      # frag.glsl:358
+    # more bounces can only add light (every term is non-negative)
+    lin5, _ = oracle.render(sc, cam, 32, 32, 2, 5, 1)
+    assert (lin5[..., :3] >= lin[..., :3]).all()
