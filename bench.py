@@ -3,13 +3,15 @@
 Workload (config.workload): C3 of BASELINE.md -- the "Sponza-class" scene the north_star target
 (>= 1 Gray/s closest-hit per MI355X) is quoted on.  The real Sponza mesh is not in the reference and
 cannot be fetched, so the scene is the labelled procedural stand-in of SURVEY.md 8(d): 8 x 8
-sphereGeometry(45,45) in a closed room = 259,212 triangles.  One step = one 3840x2160 frame at 4 spp:
-  1. jittered primary rays generated on device + closest hit   (k_primary, 33.2 M rays, coherent)
-  2. cosine-weighted bounce rays from the hits                  (k_bounce)
-  3. closest hit of the bounce rays                             (k_trace, 33.2 M rays, incoherent)
-  4. N > 1 only: all-gather of the per-rank hit slices over RCCL/xGMI and de-interleave
-Everything stays in HBM; value = closest-hit rays of the whole job / wall time (max over ranks).
-With N ranks the frame's 16-row stripes are interleaved over the ranks (strong scaling).
+sphereGeometry(45,45) in a closed room = 259,212 triangles.  One step = one 3840x2160 frame at 4 spp,
+every stage on device, nothing skipped:
+  1. k_primary      jittered primary rays generated on device + closest hit    (33.2 M rays, coherent)
+  2. k_shade        emission + Cook-Torrance throughput + cosine-weighted bounce ray (frag.glsl:310-350)
+  3. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent)
+  4. k_shade        radiance of the second segment;  k_resolve -> RGBA8 framebuffer (frag.glsl:357-359)
+  5. N > 1 only: all-gather of the per-rank framebuffer stripes over RCCL/xGMI + de-interleave
+value = closest-hit rays of the whole job / wall time (max over ranks).  With N ranks the frame's 16-row
+stripes are interleaved over the ranks (BVH replicated): total work is fixed, so scaling is "strong".
 
 Usage: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run.
 """
@@ -31,8 +33,11 @@ from raytracer_amd import dist as rd            # noqa: E402
 from raytracer_amd import scenes                # noqa: E402
 
 W, H, SPP, SEED, STRIPE = 3840, 2160, 4, 1, 16
-PEAK_VALU_TFLOPS = 157.3      # MI355X fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
-PEAK_HBM_GBS = 8000.0         # HBM3E spec peak (same table); 6.29 TB/s measured achievable
+# MI355X_MICROARCH.md, chip-level parameters: 157.3 TFLOP/s fp32 vector peak (that figure counts packed
+# v_pk_fma_f32; plain wave64 VALU issues one instruction per 4 cycles per SIMD = 78.6 TFLOP/s of scalar fma),
+# 8 TB/s HBM3E spec (6.29 TB/s measured achievable).
+PEAK_VALU_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 CPU_SAMPLE = 65536            # rays per generation in the CPU-baseline / parity sample
 
 
@@ -51,6 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal", type=int, default=rt.TRAVERSAL_BVH, help="2 = BVH2 nodes, 3 = BVH4q nodes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -60,114 +66,133 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")             # "gloo": rehearsal of N ranks on ONE GPU
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     # ---- scene setup: flatten + upload to this rank's HBM (BVH replicated per GPU) -------------------
     tris, sph, lights, cam = scenes.sponza_class()
     r = rt.Renderer((local_rank,))
-    r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    r.set_option(rt.OPT_TRAVERSAL, args.traversal)
     stats = r.create_data(tris, sph, lights)
     r.update_camera(cam)
 
     plan = rd.stripe_plan(H, world, rank, STRIPE)
     n_local = plan.padded_rows * W * SPP                 # local ray slots (padding rows are dead rays)
-    rays_per_step = W * H * SPP * 2                      # whole job: primary + bounce
+    n_px = plan.padded_rows * W
+    rays_per_step = W * H * SPP * 2                      # whole job: primary + bounce closest-hit rays
     f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
     rays, brays = f32(n_local * 8), f32(n_local * 8)
-    hits = f32(n_local * 2 * 4)                          # [primary | bounce] hit records, gathered as one buffer
-    phits, bhits = hits[: n_local * 4], hits[n_local * 4:]
+    phits, bhits = f32(n_local * 4), f32(n_local * 4)
+    thr, rad = f32(n_local * 4), f32(n_local * 4)
+    fb = torch.empty(n_px, dtype=torch.int32, device=dev)            # RGBA8 framebuffer stripes of this rank
     gidx = rd.gather_index(plan, dev) if world > 1 else None
     stream = torch.cuda.current_stream()
+    row_len = W * SPP
+    key0 = plan.y0 * row_len                                         # RNG key = path index in the full frame
 
     def stage_primary():
+        r.path_init_dev(n_local, thr, rad, stream=stream)
         r.trace_primary_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, world, phits, rays, spp=SPP, seed=SEED,
                                     jitter=True, stream=stream)
 
-    def stage_bounce_gen():
-        r.bounce_dev(rays, phits, n_local, brays, key0=0, seed=SEED, stream=stream)
+    def stage_shade1():
+        r.shade_stripes_dev(rays, phits, n_local, thr, rad, brays, key0, row_len, STRIPE, world, seed=SEED + 1, stream=stream)
 
     def stage_bounce_trace():
         r.trace_dev(brays, n_local, bhits, stream=stream)
 
+    def stage_shade2_resolve():
+        r.shade_stripes_dev(brays, bhits, n_local, thr, rad, None, key0, row_len, STRIPE, world, seed=SEED + 2, stream=stream)
+        r.resolve_dev(rad, n_px, SPP, None, fb, stream=stream)
+
     def stage_gather():
         if world == 1:
-            return None
-        both = hits.view(2, plan.padded_rows, W * SPP * 4).transpose(0, 1).contiguous()   # rows first
-        return rd.gather_rows(both, plan, gidx)                                         # [H, 2, W*SPP*4]
+            return fb
+        if backend != "nccl":                                                    # rehearsal: stage through the host
+            return rd.gather_rows(fb.view(plan.padded_rows, W).cpu(), plan, gidx.cpu())
+        return rd.gather_rows(fb.view(plan.padded_rows, W), plan, gidx)          # [H, W] RGBA8 on every rank
+
+    stages = [stage_primary, stage_shade1, stage_bounce_trace, stage_shade2_resolve, stage_gather]
 
     def step():
-        stage_primary()
-        stage_bounce_gen()
-        stage_bounce_trace()
-        return stage_gather()
+        for st in stages:
+            out = st()
+        return out
 
     # ---- instrumented pass: B, N, T per ray (same kernels with counters on) --------------------------
     r.set_option(rt.OPT_COUNTERS, 1)
     r.counters()
     stage_primary(); torch.cuda.synchronize()
     c_primary = r.counters()
-    stage_bounce_gen(); stage_bounce_trace(); torch.cuda.synchronize()
+    stage_shade1(); stage_bounce_trace(); torch.cuda.synchronize()
     c_bounce = r.counters()
     r.set_option(rt.OPT_COUNTERS, 0)
 
     # ---- warmup, then exactly K timed steps ------------------------------------------------------------
     for _ in range(args.warmup):
         step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    ne = len(stages) + 1
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(ne)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)
-        stage_primary()
-        ev[k][1].record(stream)
-        stage_bounce_gen()
-        ev[k][2].record(stream)
-        stage_bounce_trace()
-        ev[k][3].record(stream)
-        stage_gather()
+        for j, st in enumerate(stages):
+            st()
+            ev[k][j + 1].record(stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms_primary = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
-    ms_bgen = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
-    ms_btrace = float(np.mean([ev[k][2].elapsed_time(ev[k][3]) for k in range(args.steps)]))
+    ms = [float(np.mean([ev[k][j].elapsed_time(ev[k][j + 1]) for k in range(args.steps)])) for j in range(len(stages))]
+    ms_primary, ms_shade1, ms_btrace, ms_shade2, ms_gather = ms
 
+    frame = step()                                       # one more (untimed) frame for the checksum below
+    torch.cuda.synchronize()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+    import hashlib
+    frame_sha = hashlib.sha256(frame.reshape(-1)[: W * H].cpu().numpy().tobytes()).hexdigest()
 
     value = rays_per_step * args.steps / elapsed / 1e6
     n_real_local = c_primary["rays"]                     # live rays this rank traces per generation
     fl_p, by_p, w_p = flops_bytes_per_ray(c_primary, True)
     fl_b, by_b, w_b = flops_bytes_per_ray(c_bounce, False)
     live_b = c_bounce["rays"]
-    # dominant kernel = the incoherent bounce closest-hit launch (k_trace)
+    # dominant kernel = the incoherent bounce closest-hit launch (k_trace_strip)
     ach_tflops = fl_b * live_b / (ms_btrace * 1e-3) / 1e12
     ach_gbs = by_b * live_b / (ms_btrace * 1e-3) / 1e9
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and world == 1:
         try:
             pmc = json.load(open(pmc_path)).get("k_trace_hbm_bytes_per_launch")
         except Exception:
             pmc = None
-    roofline = {"bound": "valu", "kernel": "k_trace<bvh2> (bounce closest-hit)", "achieved": round(ach_tflops, 3),
+    kname = "k_trace_strip<%s> (bounce closest-hit)" % ("bvh4q" if args.traversal == 3 else "bvh2")
+    roofline = {"bound": "valu", "kernel": kname, "achieved": round(ach_tflops, 3),
                 "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / PEAK_VALU_TFLOPS, 4),
                 "traffic": pmc, "flops_per_ray": round(fl_b, 1), "work_per_ray": w_b,
-                "launch_ms": round(ms_btrace, 4), "rays_per_launch": int(live_b)}
-    roofline_hbm = {"bound": "hbm", "kernel": roofline["kernel"], "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS,
+                "launch_ms": round(ms_btrace, 4), "rays_per_launch": int(live_b),
+                "note": "fp32 VALU roofline (SURVEY 8d: never MFMA); measured VALU issue occupancy is in profiles/"}
+    roofline_hbm = {"bound": "hbm", "kernel": kname, "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(ach_gbs / PEAK_HBM_GBS, 4), "traffic": pmc,
                     "bytes_per_ray": round(by_b, 1),
                     "note": "algorithmic bytes are an upper bound on HBM traffic: the 33 MB structure is L2/MALL resident"}
@@ -177,15 +202,19 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3 sponza-class stand-in (8x8 sphereGeometry(45,45) in a room, 259212 tris), "
-                               "3840x2160 x 4 spp jittered primary + 1 cosine-weighted bounce, closest-hit",
+                               "3840x2160 x 4 spp jittered primary + 1 cosine-weighted bounce, closest-hit + shading "
+                               "to an RGBA8 framebuffer",
                    "rays_per_step": rays_per_step, "parallelism": f"stripes{STRIPE}x{world}",
-                   "bvh": {"nodes": stats["n_nodes"], "depth": stats["max_depth"], "node_bytes": stats["node_bytes"],
+                   "bvh": {"layout": "bvh4q" if args.traversal == 3 else "bvh2", "nodes": stats["n_nodes"],
+                           "depth": stats["max_depth"], "node_bytes": stats["node_bytes"],
                            "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
+        "frame_sha256": frame_sha,       # RGBA8 framebuffer: identical for every N (decomposition-invariant RNG keys)
         "roofline": roofline, "roofline_hbm": roofline_hbm,
         "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_ms": round(ms_primary, 4),
                     "primary_work_per_ray": w_p, "primary_tflops": round(fl_p * n_real_local / (ms_primary * 1e-3) / 1e12, 3),
-                    "bounce_gen_ms": round(ms_bgen, 4),
-                    "bounce_Mrays_s": round(live_b / ms_btrace / 1e3, 1), "bounce_ms": round(ms_btrace, 4)},
+                    "shade1_ms": round(ms_shade1, 4),
+                    "bounce_Mrays_s": round(live_b / ms_btrace / 1e3, 1), "bounce_ms": round(ms_btrace, 4),
+                    "shade2_resolve_ms": round(ms_shade2, 4), "gather_ms": round(ms_gather, 4)},
     }
 
     # ---- CPU baseline (oracle = reference semantics, brute force) + parity gate on the same sample --------

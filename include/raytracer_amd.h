@@ -159,9 +159,16 @@ int  rt_path_init_dev(rt_ctx* ctx, int slot, uint64_t n, float* d_throughput4, f
 /* One iteration of main()'s bounce loop (frag.glsl:310-354) for n path segments: emission (:313), every
  * light's shadow test + Cook-Torrance term (:319-338), the next cosine-weighted ray (:340-343) and the
  * throughput update (:345-350).  A miss ends the path: the output ray is dead (tmax 0).
- * RNG key of element i = key0 + i. */
+ * RNG key of element i = key0 + i.  d_rays_out may be NULL for the last segment of a path: then only the
+ * radiance is updated (no next ray, no throughput update). */
 int  rt_shade_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
                   uint32_t seed, float* d_throughput4, float* d_radiance4, rt_ray* d_rays_out, void* stream);
+/* Same for an interleaved share of a frame (see rt_trace_primary_stripes_dev): local element i lies in local row
+ * yl = i / row_len (row_len = w*spp); its RNG key is key0 + (image row of yl relative to y0) * row_len + i % row_len,
+ * i.e. with key0 = y0*row_len the index of the path in the full frame -- a striped render draws the same numbers. */
+int  rt_shade_stripes_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
+                          uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed,
+                          float* d_throughput4, float* d_radiance4, rt_ray* d_rays_out, void* stream);
 /* frag.glsl:357-359: per pixel, sum of its spp radiance records / spp, then pow(c, 1/2.6) -> RGBA8 (a = 255).
  * d_linear4 (4 floats per pixel, pre-gamma) and d_rgba8 may each be NULL, not both. */
 int  rt_resolve_dev(rt_ctx* ctx, int slot, const float* d_radiance4, uint64_t n_pixels, uint32_t spp,

@@ -209,6 +209,12 @@ class Renderer:
         self._check(self._lib.rt_shade_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, key0, seed, _ptr(throughput),
                                            _ptr(radiance), _ptr(out_rays), _stream_ptr(stream)))
 
+    def shade_stripes_dev(self, rays, hits, n, throughput, radiance, out_rays, key0, row_len, stripe_h, stripe_step,
+                          seed=0, slot=0, stream=None):
+        self._check(self._lib.rt_shade_stripes_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, key0, row_len, stripe_h,
+                                                   stripe_step, seed, _ptr(throughput), _ptr(radiance), _ptr(out_rays),
+                                                   _stream_ptr(stream)))
+
     def resolve_dev(self, radiance, n_pixels, spp, linear=None, rgba8=None, slot=0, stream=None):
         self._check(self._lib.rt_resolve_dev(self._ctx, slot, _ptr(radiance), n_pixels, spp, _ptr(linear), _ptr(rgba8),
                                              _stream_ptr(stream)))

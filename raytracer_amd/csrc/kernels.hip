@@ -637,6 +637,7 @@ __device__ __forceinline__ f3 hemisphere(f3 N, float xi1, float xi2) {          
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
                                                   const float4* __restrict__ hits, uint64_t n, uint32_t key0,
+                                                  uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step,
                                                   uint32_t seed, float4* __restrict__ thr, float4* __restrict__ rad,
                                                   float4* __restrict__ out) {
     extern __shared__ int stack[];
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __re
     f3 P, N;
     f3 d = mk(r1.x, r1.y, r1.z);
     if (!(r1.w > r0.w) || !hit_point(s, mk(r0.x, r0.y, r0.z), d, hit, P, N)) {     // :351-353 the path ends
-        out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0);
+        if (out) { out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0); }
         return;
     }
     const uint32_t prim = __float_as_uint(hit.w);
@@ -683,7 +684,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __re
                    __fmaf_rn((T.z * B.z) * (l1.z * ia), NdotL, C.z));                // :335-336
         }
     }
-    const uint32_t key = key0 + (uint32_t)i;
+    if (out == nullptr) {                  // last segment of a path: only its radiance is still needed
+        rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
+        return;
+    }
+    // RNG key = index of this path in the FULL frame, so that a striped share draws the same numbers
+    uint32_t key = key0 + (uint32_t)i;
+    if (row_len) {
+        const uint32_t yl = (uint32_t)(i / row_len), rem = (uint32_t)(i - (uint64_t)yl * row_len);
+        key = key0 + ((yl / stripe_h) * stripe_h * stripe_step + yl % stripe_h) * row_len + rem;
+    }
     f3 dir = hemisphere(N, rand01(key, 2u, seed), rand01(key, 3u, seed));           // :340
     f3 o = madd3(0.001f, N, P);                                                     // :342
     float NdotR = max0(dot3(N, dir));                                               // :345
@@ -797,15 +807,16 @@ hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, cons
 }
 
 hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
-                        uint32_t key0, uint32_t seed, float4* d_throughput, float4* d_radiance, rt_ray* d_out,
-                        hipStream_t st) {
+                        uint32_t key0, uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed,
+                        float4* d_throughput, float4* d_radiance, rt_ray* d_out, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    if (row_len && (stripe_h == 0 || stripe_step == 0)) return hipErrorInvalidValue;
     dim3 g(grid_for(n)), b(kBlock);
     const float4* hits = reinterpret_cast<const float4*>(d_hits);
     float4* out = reinterpret_cast<float4*>(d_out);
     // the traversal inside k_shade only runs when the scene has lights
     const int m = s.n_lights ? mode : kBrute;
-#define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shade<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, seed, d_throughput, d_radiance, out)
+#define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shade<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, row_len, stripe_h, stripe_step, seed, d_throughput, d_radiance, out)
     if (m == kBrute) RT_LAUNCH_M(kBrute); else if (m == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH_M
     return hipGetLastError();

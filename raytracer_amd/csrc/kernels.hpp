@@ -46,8 +46,8 @@ hipError_t launch_bounce(const DevScene& s, const rt_ray* d_rays, const rt_hit* 
 
 // frag.glsl:310-354, one bounce of the path loop for a batch (emission, direct light, next ray, throughput)
 hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
-                        uint32_t key0, uint32_t seed, float4* d_throughput, float4* d_radiance, rt_ray* d_out,
-                        hipStream_t st);
+                        uint32_t key0, uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed,
+                        float4* d_throughput, float4* d_radiance, rt_ray* d_out, hipStream_t st);
 // frag.glsl:357-359: average over spp, gamma 1/2.6, RGBA8 (+ optional linear float4)
 hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t spp, float4* d_linear, uint32_t* d_rgba8,
                           hipStream_t st);

@@ -466,12 +466,18 @@ int rt_bounce_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
 
 int rt_shade_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
                  uint32_t seed, float* d_throughput4, float* d_radiance4, rt_ray* d_out, void* stream) {
+    return rt_shade_stripes_dev(c, slot, d_rays, d_hits, n, key0, 0, 1, 1, seed, d_throughput4, d_radiance4, d_out, stream);
+}
+
+int rt_shade_stripes_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
+                         uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed, float* d_throughput4,
+                         float* d_radiance4, rt_ray* d_out, void* stream) {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
-    if (n && (!d_rays || !d_hits || !d_throughput4 || !d_radiance4 || !d_out)) return fail(c, RT_E_INVALID, "shade: null device pointer");
+    if (n && (!d_rays || !d_hits || !d_throughput4 || !d_radiance4)) return fail(c, RT_E_INVALID, "shade: null device pointer");
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
-    RT_HIP(c, launch_shade(c->dev_scene(r), c->mode(), d_rays, d_hits, n, key0, seed, reinterpret_cast<float4*>(d_throughput4),
+    RT_HIP(c, launch_shade(c->dev_scene(r), c->mode(), d_rays, d_hits, n, key0, row_len, stripe_h, stripe_step, seed, reinterpret_cast<float4*>(d_throughput4),
                            reinterpret_cast<float4*>(d_radiance4), d_out, (hipStream_t)stream));
     return RT_OK;
 }
@@ -538,7 +544,7 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, ra, hits, r.d_counters, r.stream));
         const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
         for (uint32_t b = 0; b < bounces; ++b) {
-            RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, seed + 1u + b, thr, rad, rb, r.stream));
+            RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, 0, 1, 1, seed + 1u + b, thr, rad, b + 1 < bounces ? rb : nullptr, r.stream));
             if (b + 1 < bounces)
                 RT_HIP_SLOT(r, launch_trace(ds, mode, false, false, rb, n, hits, nullptr, r.d_counters, r.stream, c->strip, c->refill));
             std::swap(ra, rb);
