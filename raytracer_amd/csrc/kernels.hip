@@ -114,10 +114,12 @@ __device__ __forceinline__ void trace_brute(const DevScene& s, f3 o, f3 d, float
 // Box planes are padded at build time (DESIGN.md "Conservative traversal"), so the slab test may use
 // the single-fma form t = plane*idir + (-o*idir).  A node is entered when tn <= tf with tf clipped to
 // the current best t: equality is NOT culled, which the tie rule needs.
+// 1/d for the slab test only (never for hit records): v_rcp_f32 is within 1 ulp, which the box padding
+// covers (DESIGN.md "Conservative traversal"), and costs one instruction instead of the ~10 of an IEEE divide.
 __device__ __forceinline__ float safe_rcp(float d) {
     const float tiny = 0x1.0p-80f;
     float dd = fabsf(d) > tiny ? d : copysignf(tiny, d);
-    return 1.0f / dd;
+    return __builtin_amdgcn_rcpf(dd);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     Best b = { 0.0f, 0.0f, 0.0f, 0u };
     Counters c = { 0, 0, 0, 0 };
     uint32_t n_mine = 0;
+    uint32_t w_rounds = 0, w_i = 0, w_texec = 0, w_t = 0;    // wave-uniform scheduling probes (COUNT builds)
     for (;;) {
         const bool idle = node == kDone;
         const unsigned long long im = __ballot(idle);
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
         if (need_i) node = bvh_step<MODE, COUNT>(nodes, node, sl, tmin0, b.t, stk, sp, c);
         const bool need_t = node < 0 && node != kDone;
         const unsigned long long mt = __ballot(need_t);
+        if (COUNT) { ++w_rounds; w_i += __popcll(mi); }
         if (__popcll(mt) >= tth || mi == 0ull) {
+            if (COUNT) { ++w_texec; w_t += __popcll(mt); }
             if (need_t) {
                 const uint32_t ref = ~(uint32_t)node;              // (first << 3) | (remaining - 1)
                 const float4* tp = tris + (size_t)(ref >> 3) * 3;
@@ -429,6 +434,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
             #pragma unroll
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters[k], (unsigned long long)x);
+        }
+        if ((threadIdx.x & 63) == 0) {       // scheduling probes of this kernel (they reuse the divergence slots):
+            atomicAdd(&counters[7], (unsigned long long)w_rounds);      // waves      <- scheduling rounds
+            atomicAdd(&counters[5], (unsigned long long)w_i);           // wave_max_nodes <- lanes active in interior blocks
+            atomicAdd(&counters[6], (unsigned long long)w_t);           // wave_max_tris  <- lanes active in triangle blocks
         }
     }
 }

@@ -15,4 +15,5 @@ for name in ("primary","bounce"):
     if name=="primary":
         r.bounce_dev(rays,hits,n,brays,seed=1); r.trace_dev(brays,n,bhits); torch.cuda.synchronize()
     else: pass
-    print(name, c, "mean nodes/ray %.1f  wave-max nodes %.1f  mean tris %.2f wave-max tris %.1f" % (c['nodes']/c['rays'], c['wave_max_nodes']/c['waves'], c['tri_tests']/c['rays'], c['wave_max_tris']/c['waves']))
+    if name=='bounce': print('rounds/wave-strip: rounds %d  I-lanes/round %.1f  T-runs %d (%.2f of rounds) T-lanes/run %.1f' % (c['waves'], c['wave_max_nodes']/c['waves'], c['sphere_tests'], c['sphere_tests']/c['waves'], c['wave_max_tris']/max(c['sphere_tests'],1)))
+    print(name, c, "mean nodes/ray %.1f  wave-max nodes %.1f  mean tris %.2f wave-max tris %.1f" % (c['nodes']/c['rays'], c['wave_max_nodes']/max(c['waves'],1), c['tri_tests']/c['rays'], c['wave_max_tris']/max(c['waves'],1)), 'both-miss nodes/ray %.2f' % (c['sphere_tests']/c['rays']))

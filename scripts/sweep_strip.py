@@ -18,9 +18,9 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/reps
 print("plain k_trace: %.3f ms" % timeit(lambda: r.trace_dev(brays,n,bhits)))
-for strip in (512, 1024):
-  for tth in (0, 4, 8, 16, 24, 32):
-    for refill in (8, 16, 32):
+for strip in (512, 1024, 2048):
+  for tth in (8, 16, 24):
+    for refill in (8, 16, 24, 32):
         r.set_option(rt.OPT_STRIP, strip); r.set_option(rt.OPT_REFILL, refill | (tth << 8))
         ms = timeit(lambda: r.trace_dev(brays,n,bhits))
         ok = torch.equal(bhits.view(torch.int32), ref.view(torch.int32))
