@@ -108,6 +108,12 @@ int  rt_scene_upload(rt_ctx* ctx,
                      const void* spheres, uint32_t n_spheres, uint32_t sphere_stride,
                      const void* lights,  uint32_t n_lights,  uint32_t light_stride);
 int  rt_scene_stats_get(const rt_ctx* ctx, rt_scene_stats* out);
+/* The host half of rt_scene_upload on its own (no device needed): BVH build + flatten.  layout 2 = BVH2 nodes,
+ * 3 = BVH4q nodes (16 words per node, DESIGN.md "Data layout").  nodes_out / tri_order_out may be NULL (then only
+ * the statistics are produced); for layout 3 stats->n_lights carries the traversal-stack bound. */
+int  rt_bvh_build_host(const void* tris, uint32_t n_tris, uint32_t tri_stride, int layout, int max_leaf, int pad_log2,
+                       int threads, rt_scene_stats* stats, uint32_t* nodes_out, uint64_t nodes_cap_words,
+                       uint32_t* tri_order_out);
 
 /* ---- camera (per frame) ------------------------------------------------------------------------
  * Replaces VkRenderer::updateUniformBuffer (src/vulkan/VkRenderer.cpp:855-862): 112-byte

@@ -81,6 +81,27 @@ def default_camera(aspect=1200.0 / 1000.0):
     return camera_look_at((0.0, 4.0, 1.0), (0.0, 0.0, 1.0), 45.0, aspect)
 
 
+def bvh_build_host(triangles, layout=TRAVERSAL_BVH2, max_leaf=4, pad_log2=15, threads=0, want_nodes=True):
+    """Host-only BVH build + flatten (rt_bvh_build_host): (stats dict, nodes uint32[n_nodes,16], tri_order)."""
+    t = np.ascontiguousarray(triangles)
+    st = rt_scene_stats()
+    L = lib()
+    rc = L.rt_bvh_build_host(_ptr(t) if len(t) else None, len(t), TRIANGLE.itemsize, layout, max_leaf, pad_log2, threads,
+                             C.byref(st), None, 0, None)
+    if rc != 0:
+        raise RuntimeError(f"rt_bvh_build_host failed ({rc})")
+    stats = {f: getattr(st, f) for f, _ in st._fields_}
+    if not want_nodes:
+        return stats, None, None
+    nodes = np.zeros((max(st.n_nodes, 1), 16), dtype=np.uint32)
+    order = np.zeros(max(len(t), 1), dtype=np.uint32)
+    rc = L.rt_bvh_build_host(_ptr(t) if len(t) else None, len(t), TRIANGLE.itemsize, layout, max_leaf, pad_log2, threads,
+                             C.byref(st), _ptr(nodes), nodes.size, _ptr(order))
+    if rc != 0:
+        raise RuntimeError(f"rt_bvh_build_host failed ({rc})")
+    return stats, nodes[: st.n_nodes], order[: len(t)]
+
+
 class Renderer:
     """Owner of an rt_ctx: the compute-side stand-in for VkRenderer's scene/camera/draw seams."""
 

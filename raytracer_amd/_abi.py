@@ -36,6 +36,7 @@ SYMBOLS = [
     ("rt_num_slots", _I, [_P]),
     ("rt_scene_upload", _I, [_P, _P, _U32, _U32, _P, _U32, _U32, _P, _U32, _U32]),
     ("rt_scene_stats_get", _I, [_P, C.POINTER(rt_scene_stats)]),
+    ("rt_bvh_build_host", _I, [_P, _U32, _U32, _I, _I, _I, _I, C.POINTER(rt_scene_stats), _P, _U64, _P]),
     ("rt_set_camera", _I, [_P, _P]),
     ("rt_trace_primary", _I, [_P, _U32, _U32, _P]),
     ("rt_trace", _I, [_P, _P, _U64, _P]),

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     Best b = { 0.0f, 0.0f, 0.0f, 0u };
     Counters c = { 0, 0, 0, 0 };
     uint32_t n_mine = 0;
-    uint32_t w_rounds = 0, w_i = 0, w_texec = 0, w_t = 0;    // wave-uniform scheduling probes (COUNT builds)
+    uint32_t w_rounds = 0, w_i = 0, w_t = 0;    // wave-uniform scheduling probes (COUNT builds)
     for (;;) {
         const bool idle = node == kDone;
         const unsigned long long im = __ballot(idle);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
         const unsigned long long mt = __ballot(need_t);
         if (COUNT) { ++w_rounds; w_i += __popcll(mi); }
         if (__popcll(mt) >= tth || mi == 0ull) {
-            if (COUNT) { ++w_texec; w_t += __popcll(mt); }
+            if (COUNT) w_t += __popcll(mt);
             if (need_t) {
                 const uint32_t ref = ~(uint32_t)node;              // (first << 3) | (remaining - 1)
                 const float4* tp = tris + (size_t)(ref >> 3) * 3;

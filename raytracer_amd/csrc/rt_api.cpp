@@ -360,6 +360,59 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     return RT_OK;
 }
 
+// Host-only BVH build + flatten (no device): what rt_scene_upload runs before copying to HBM.
+int rt_bvh_build_host(const void* tris, uint32_t n_tris, uint32_t tri_stride, int layout, int max_leaf, int pad_log2,
+                      int threads, rt_scene_stats* stats, uint32_t* nodes_out, uint64_t nodes_cap_words,
+                      uint32_t* tri_order_out) {
+    if (!stats || (n_tris && (!tris || tri_stride < sizeof(Triangle) || (tri_stride & 3)))) return RT_E_INVALID;
+    if (n_tris >= (1u << 28)) return RT_E_TOO_LARGE;
+    if (layout != kBvh2 && layout != kBvh4q) return RT_E_INVALID;
+    const double t0 = now_ms();
+    std::vector<Aabb> boxes(n_tris);
+    float maxabs = 0.f;
+    const char* tb = static_cast<const char*>(tris);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Aabb b; b.reset();
+        for (int v = 0; v < 3; ++v) {
+            float p[3];
+            std::memcpy(p, tb + (size_t)i * tri_stride + 32 * v, 12);
+            for (int a = 0; a < 3; ++a) { if (!std::isfinite(p[a])) return RT_E_INVALID; maxabs = std::max(maxabs, std::fabs(p[a])); }
+            b.grow(p);
+        }
+        boxes[i] = b;
+    }
+    BuildParams bp;
+    bp.max_leaf = max_leaf > 0 ? max_leaf : 4;
+    bp.max_depth = kStackDepth - 2;
+    bp.threads = threads;
+    BuildResult br;
+    build_bvh2(boxes.data(), n_tris, bp, br);
+    const float pad = std::ldexp(std::max(maxabs, 1e-30f), -(pad_log2 > 0 ? pad_log2 : 15));
+    *stats = rt_scene_stats{};
+    stats->n_tris = n_tris; stats->sah_cost = br.sah_cost; stats->node_bytes = 64; stats->tri_bytes = 48;
+    std::vector<uint32_t> words, order;
+    if (layout == kBvh2) {
+        FlatBvh2 f; flatten_bvh2(br, n_tris ? pad : 0.f, f);
+        words.resize(f.nodes.size());
+        if (!f.nodes.empty()) std::memcpy(words.data(), f.nodes.data(), f.nodes.size() * 4);
+        order.swap(f.tri_order);
+        stats->n_nodes = f.n_nodes; stats->n_leaves = f.n_leaves; stats->max_depth = f.depth;
+    } else {
+        FlatBvh4q f; flatten_bvh4q(br, n_tris ? pad : 0.f, f);
+        words.swap(f.nodes); order.swap(f.tri_order);
+        stats->n_nodes = f.n_nodes; stats->n_leaves = f.n_leaves; stats->max_depth = f.depth;
+        stats->n_lights = f.stack_need;          // host-only entry: reports the 4-wide stack bound here
+    }
+    stats->build_ms = (float)(now_ms() - t0);
+    stats->device_bytes = (uint64_t)words.size() * 4 + (uint64_t)n_tris * 96;
+    if (nodes_out) {
+        if (nodes_cap_words < words.size()) return RT_E_TOO_LARGE;
+        if (!words.empty()) std::memcpy(nodes_out, words.data(), words.size() * 4);
+    }
+    if (tri_order_out && !order.empty()) std::memcpy(tri_order_out, order.data(), order.size() * 4);
+    return RT_OK;
+}
+
 int rt_scene_stats_get(const rt_ctx* c, rt_scene_stats* out) {
     if (!c || !out) return RT_E_INVALID;
     if (!c->has_scene) return RT_E_NO_SCENE;

@@ -8,8 +8,10 @@
 #include "../../include/raytracer_amd.h"
 #include "../host/rt_types.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 using namespace rt;
@@ -71,6 +73,21 @@ inline uint64_t splitmix(uint64_t seed, uint64_t k) {       // k-th output of Sp
     return z ^ (z >> 31);
 }
 inline float u01(uint64_t seed, uint64_t k) { return (float)(splitmix(seed, k) >> 40) * 0x1.0p-24f; }
+
+// The generators are counter-based, so ranges can be filled by independent host threads.
+template <class F>
+void parallel_ranges(uint64_t n, F fn) {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nt = n < (1u << 16) ? 1u : hw;
+    if (nt == 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const uint64_t b = std::min<uint64_t>(per * t, n), e = std::min<uint64_t>(b + per, n);
+        if (b < e) th.emplace_back([=] { fn(b, e); });
+    }
+    for (auto& x : th) x.join();
+}
 
 }  // namespace
 
@@ -155,7 +172,8 @@ uint32_t rt_gen_sphere_geometry(const float center[3], float radius, uint32_t st
 uint32_t rt_gen_soup(uint64_t seed, uint32_t n, float half_extent, void* out, uint32_t cap) {
     Triangle* t = static_cast<Triangle*>(out);
     const uint32_t m = n < cap ? n : cap;
-    for (uint32_t i = 0; i < m; ++i) {
+    parallel_ranges(m, [=](uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; ++i) {
         const uint64_t b = 12ull * i;
         Vec3 c = { u01(seed, b), u01(seed, b + 1), u01(seed, b + 2) };
         Vec3 p[3];
@@ -171,13 +189,15 @@ uint32_t rt_gen_soup(uint64_t seed, uint32_t n, float half_extent, void* out, ui
         Vec3 nn = l2 > 0.f ? normalized(g) : Vec3{ 0.f, 0.f, 1.f };
         t[i] = make_tri(p[0], p[1], p[2], nn, nn, nn, kWhite);
     }
+    });
     return n;
 }
 
 // SURVEY.md 8(d) C4 rays: origin uniform in [0,1)^3, direction uniform on the sphere (normalised
 // Gaussian triple via Box-Muller), tmin 1e-6, tmax 1e20.  8 draws per ray, counter-based.
 void rt_gen_random_rays(uint64_t seed, uint64_t first, uint64_t n, rt_ray* out) {
-    for (uint64_t i = 0; i < n; ++i) {
+    parallel_ranges(n, [=](uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; ++i) {
         const uint64_t b = 8ull * (first + i);
         rt_ray r;
         r.ox = u01(seed, b); r.oy = u01(seed, b + 1); r.oz = u01(seed, b + 2);
@@ -194,6 +214,7 @@ void rt_gen_random_rays(uint64_t seed, uint64_t first, uint64_t n, rt_ray* out) 
         r.tmin = 1e-6f; r.tmax = 1e20f;
         out[i] = r;
     }
+    });
 }
 
 // Camera::Camera + updateCameraVectors (src/application/Camera.h:24-41): worldUp is forced to
