@@ -1,0 +1,184 @@
+"""Runs the BASELINE.json configs C1..C5 on ONE MI355X and prints one JSON line per config (results table of
+DESIGN.md).  Parity gates (prim-ID mismatches against the oracle / the brute-force HIP kernel) ride along.
+
+usage: python scripts/run_configs.py [c1 c2 c3 c4 c5] [--soup N] [--rays N]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import oracle
+import raytracer_amd as rt
+from raytracer_amd import scenes
+
+dev = torch.device("cuda", 0)
+f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def counters_of(r, fn):
+    r.set_option(rt.OPT_COUNTERS, 1); r.counters(); fn(); torch.cuda.synchronize()
+    c = r.counters(); r.set_option(rt.OPT_COUNTERS, 0)
+    rays = max(c["rays"], 1)
+    return {"B": round(c["box_tests"] / rays, 2), "N": round(c["nodes"] / rays, 2), "T": round(c["tri_tests"] / rays, 2)}
+
+
+def sample_parity(tris, sph, rays_np, hits_np, k, seed=0):
+    idx = np.sort(np.random.default_rng(seed).choice(len(rays_np), min(k, len(rays_np)), replace=False))
+    t = time.time()
+    ref = oracle.trace(oracle.Scene(tris, sph), rays_np[idx])
+    dt = time.time() - t
+    got = hits_np[idx]
+    return {"sample": int(len(idx)), "prim_id_mismatches": int((ref["prim"] != got["prim"]).sum()),
+            "bit_exact": bool(ref.tobytes() == got.tobytes()), "oracle_s": round(dt, 1),
+            "oracle_Mrays_s": round(len(idx) / dt / 1e6, 5), "oracle_threads": oracle.num_threads()}
+
+
+def out(d):
+    print(json.dumps(d), flush=True)
+
+
+def c1():
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(1.0)
+    res = {"config": "C1 Cornell 12 tris + 3 spheres, 512x512 primary"}
+    ref = oracle.trace_primary(oracle.Scene(tris, sph), cam, 512, 512)
+    for name, mode in (("brute(auto)", rt.TRAVERSAL_AUTO), ("bvh2", rt.TRAVERSAL_BVH2), ("bvh4q", rt.TRAVERSAL_BVH4Q)):
+        with rt.Renderer((0,)) as r:
+            r.set_option(rt.OPT_TRAVERSAL, mode); r.create_data(tris, sph); r.update_camera(cam)
+            hits = f32(512 * 512 * 4)
+            ms = timeit(lambda: r.trace_primary_dev(512, 512, hits), 20)
+            got = hits.cpu().numpy().view(rt.HIT).reshape(512, 512)
+            res[name] = {"ms": round(ms, 4), "Mrays_s": round(512 * 512 / ms / 1e3, 1),
+                         "full_frame_bit_exact": bool(got.tobytes() == ref.tobytes()),
+                         "prim_id_mismatches": int((got["prim"] != ref["prim"]).sum())}
+    out(res)
+
+
+def c2():
+    tris, sph, lights, cam = scenes.bunny_class()
+    w, h = 1920, 1080
+    n = w * h
+    res = {"config": f"C2 bunny-class stand-in {len(tris)} tris, 1920x1080 primary + 1 shadow ray per hit pixel"}
+    for name, mode in (("bvh2", rt.TRAVERSAL_BVH2), ("bvh4q", rt.TRAVERSAL_BVH4Q)):
+        with rt.Renderer((0,)) as r:
+            r.set_option(rt.OPT_TRAVERSAL, mode); st = r.create_data(tris, sph, lights); r.update_camera(cam)
+            rays, hits = f32(n * 8), f32(n * 4)
+            lit = torch.empty(n, dtype=torch.uint8, device=dev)
+            lp = tuple(float(x) for x in lights[0]["position"])
+            ms_p = timeit(lambda: r.trace_primary_dev(w, h, hits, rays))
+            ms_s = timeit(lambda: r.shadow_dev(rays, hits, n, lp, lit))
+            hh = hits.cpu().numpy().view(rt.HIT)
+            n_shadow = int((hh["prim"] != rt.MISS).sum())
+            par = sample_parity(tris, sph, rays.cpu().numpy().view(rt.RAY), hh, 16384)
+            idx = np.sort(np.random.default_rng(1).choice(n, 16384, replace=False))
+            o_lit = oracle.shadow_lit(oracle.Scene(tris, sph), rays.cpu().numpy().view(rt.RAY)[idx], hh[idx], lp)
+            par["shadow_flag_mismatches"] = int((o_lit != lit.cpu().numpy()[idx]).sum())
+            res[name] = {"primary_ms": round(ms_p, 4), "shadow_ms": round(ms_s, 4), "shadow_rays": n_shadow,
+                         "Mrays_s": round((n + n_shadow) / (ms_p + ms_s) / 1e3, 1),
+                         "primary_Mrays_s": round(n / ms_p / 1e3, 1), "shadow_Mrays_s": round(n_shadow / ms_s / 1e3, 1),
+                         "work_primary": counters_of(r, lambda: r.trace_primary_dev(w, h, hits, rays)),
+                         "bvh": {"nodes": st["n_nodes"], "depth": st["max_depth"], "build_ms": round(st["build_ms"], 1)},
+                         "parity": par}
+    out(res)
+
+
+def c4(n_tris, n_rays):
+    res = {"config": f"C4 random soup {n_tris} tris (half extent 0.005), {n_rays} random rays, one GPU"}
+    t = time.time(); tris = scenes.soup(n_tris); res["gen_tris_s"] = round(time.time() - t, 1)
+    t = time.time(); rays_np = scenes.random_rays(n_rays); res["gen_rays_s"] = round(time.time() - t, 1)
+    rays = torch.from_numpy(rays_np.view(np.float32).reshape(-1)).to(dev)
+    hits = f32(n_rays * 4)
+    keep = {}
+    for name, mode in (("bvh2", rt.TRAVERSAL_BVH2), ("bvh4q", rt.TRAVERSAL_BVH4Q)):
+        with rt.Renderer((0,)) as r:
+            r.set_option(rt.OPT_TRAVERSAL, mode)
+            t = time.time(); st = r.create_data(tris); up = time.time() - t
+            ms = timeit(lambda: r.trace_dev(rays, n_rays, hits), 3)
+            keep[name] = hits.cpu().numpy().view(rt.HIT).copy()
+            work = counters_of(r, lambda: r.trace_dev(rays, n_rays, hits))
+            res[name] = {"ms": round(ms, 3), "Mrays_s": round(n_rays / ms / 1e3, 1), "work": work,
+                         "alg_GBps": round((64 * work["N"] + 48 * work["T"] + 48) * n_rays / ms / 1e6, 1),
+                         "hit_fraction": round(float((keep[name]["prim"] != rt.MISS).mean()), 4),
+                         "bvh": {"nodes": st["n_nodes"], "depth": st["max_depth"], "build_ms": round(st["build_ms"], 1),
+                                 "upload_call_s": round(up, 2), "device_MB": round(st["device_bytes"] / 1e6, 1)}}
+            if name == "bvh2":
+                # mismatch rate against the reference loop on the GPU (brute force over all triangles)
+                m = min(n_rays, 1 << 17)
+                r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BRUTE)
+                bh = f32(m * 4)
+                t = time.time(); r.trace_dev(rays, m, bh); torch.cuda.synchronize(); bs = time.time() - t
+                b = bh.cpu().numpy().view(rt.HIT)
+                res["gpu_brute_check"] = {"rays": m, "seconds": round(bs, 2),
+                                          "prim_id_mismatches_bvh2": int((b["prim"] != keep["bvh2"][:m]["prim"]).sum()),
+                                          "bit_exact_bvh2": bool(b.tobytes() == keep["bvh2"][:m].tobytes())}
+                keep["brute"] = b
+    m = len(keep["brute"])
+    res["gpu_brute_check"]["prim_id_mismatches_bvh4q"] = int((keep["brute"]["prim"] != keep["bvh4q"][:m]["prim"]).sum())
+    res["layouts_agree"] = bool(keep["bvh2"].tobytes() == keep["bvh4q"].tobytes())
+    res["parity_vs_oracle"] = sample_parity(tris, None, rays_np, keep["bvh2"], 4096)
+    out(res)
+
+
+def c5(n_tris):
+    w, h, spp, bounces = 3840, 2160, 16, 3
+    res = {"config": f"C5 stand-in: C4 soup {n_tris} tris with a pinhole camera, 3840x2160 x 16 spp x 3 bounces, one GPU"}
+    tris = scenes.soup(n_tris)
+    e = tris["material"]["emission"]; e[::50] = (1.0, 0.9, 0.8); tris["material"]["emissionStrength"][::50] = 2.0   # 2 % emitters
+    cam = rt.camera_look_at((0.5, 2.2, 0.5), (0.5, 0.5, 0.5), 45.0, w / h)
+    n = w * h * spp
+    with rt.Renderer((0,)) as r:
+        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH2)
+        r.create_data(tris); r.update_camera(cam)
+        ra, rb, hits, thr, rad = f32(n * 8), f32(n * 8), f32(n * 4), f32(n * 4), f32(n * 4)
+        fb = torch.empty(w * h, dtype=torch.int32, device=dev)
+        live = []
+
+        def frame(count=False):
+            a, b = ra, rb
+            r.path_init_dev(n, thr, rad)
+            r.trace_primary_dev(w, h, hits, a, spp=spp, seed=1, jitter=True)
+            for k in range(bounces):
+                if count:
+                    live.append(int((a.view(-1, 8)[:, 7] > 0).sum()))
+                last = k + 1 == bounces
+                r.shade_dev(a, hits, n, thr, rad, None if last else b, key0=0, seed=2 + k)
+                if not last:
+                    r.trace_dev(b, n, hits)
+                    a, b = b, a
+            r.resolve_dev(rad, w * h, spp, None, fb)
+        frame(True); torch.cuda.synchronize()
+        ms = timeit(frame, 2)
+        traced = sum(live)
+        res.update({"frame_ms": round(ms, 2), "closest_hit_rays": traced, "Mrays_s": round(traced / ms / 1e3, 1),
+                    "live_rays_per_segment": live, "nonblack_pixels": int((fb.cpu().numpy() & 0xFFFFFF != 0).sum())})
+    out(res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["c1", "c2", "c4", "c5"])
+    ap.add_argument("--soup", type=int, default=10_000_000)
+    ap.add_argument("--rays", type=int, default=64 * (1 << 20))
+    a = ap.parse_args()
+    for w in a.which:
+        {"c1": c1, "c2": c2, "c4": lambda: c4(a.soup, a.rays), "c5": lambda: c5(a.soup)}[w]()
+
+
+if __name__ == "__main__":
+    main()
