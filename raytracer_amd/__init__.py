@@ -39,7 +39,7 @@ assert RAY.itemsize == 32 and HIT.itemsize == 16
 
 OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL = 1, 2, 3, 4, 5, 6, 7
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
-TRAVERSAL_BVH = TRAVERSAL_BVH2
+TRAVERSAL_BVH = TRAVERSAL_BVH4Q
 
 
 def lib():

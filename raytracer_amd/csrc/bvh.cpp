@@ -404,6 +404,9 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
         for (int k = 0; k < 4; ++k) {
             int32_t r = (k < w.n) ? ref[w.child[k]] : leaf_ref(0, 1);
             std::memcpy(&q[4 + k], &r, 4);
+            if (k >= w.n) {                                   // empty slot: inverted box (lo 255, hi 0) never hits
+                for (int a = 0; a < 3; ++a) q[8 + a] |= 0xffu << (8 * k);
+            }
         }
     }
 }

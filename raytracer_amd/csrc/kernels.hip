@@ -184,8 +184,8 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     const int popped = stk[(sp - 1) * kBlock];
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 q3 = *reinterpret_cast<const uint2*>(np + 3);
-    const uint32_t w = q0.w, n = w >> 24;
-    if (COUNT) { ++c.nodes; c.box += n; }
+    const uint32_t w = q0.w;
+    if (COUNT) { ++c.nodes; c.box += w >> 24; }
     const float idx = sl.ix.x, idy = sl.iy.x, idz = sl.iz.x;
     const float sx = __uint_as_float((w << 23) & 0x7f800000u) * idx;
     const float sy = __uint_as_float((w << 15) & 0x7f800000u) * idy;
@@ -195,20 +195,23 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     const float az = __fmaf_rn(__uint_as_float(q0.z), idz, sl.oz.x);
     const v2f sx2 = (v2f){ sx, sx }, sy2 = (v2f){ sy, sy }, sz2 = (v2f){ sz, sz };
     const v2f ax2 = (v2f){ ax, ax }, ay2 = (v2f){ ay, ay }, az2 = (v2f){ az, az };
+    // The ray's direction signs pick, once per node and for all four children, which plane word is the entry
+    // side and which the exit side: no per-axis min/max later.  Empty slots are stored inverted (lo 255, hi 0),
+    // so their entry lies behind their exit whatever the signs and they miss without a count check.
+    const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;
+    const uint32_t ex = nx ? q2.w : q2.x, fx = nx ? q2.x : q2.w;      // entry / exit plane bytes, x
+    const uint32_t ey = ny ? q3.x : q2.y, fy = ny ? q2.y : q3.x;
+    const uint32_t ez = nz ? q3.y : q2.z, fz = nz ? q2.z : q3.y;
     uint32_t key[4];
     int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
     #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float lx = (float)((q2.x >> (8 * k)) & 0xffu), ly = (float)((q2.y >> (8 * k)) & 0xffu);
-        const float lz = (float)((q2.z >> (8 * k)) & 0xffu), hx = (float)((q2.w >> (8 * k)) & 0xffu);
-        const float hy = (float)((q3.x >> (8 * k)) & 0xffu), hz = (float)((q3.y >> (8 * k)) & 0xffu);
-        const v2f tx = __builtin_elementwise_fma((v2f){ lx, hx }, sx2, ax2);
-        const v2f ty = __builtin_elementwise_fma((v2f){ ly, hy }, sy2, ay2);
-        const v2f tz = __builtin_elementwise_fma((v2f){ lz, hz }, sz2, az2);
-        const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin0));
-        const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), bt));
-        const bool hit = (tn <= tf) & ((uint32_t)k < n);
-        key[k] = hit ? __float_as_uint(tn) : 0xffffffffu;          // tn >= tmin0 >= 0: bits order like the value
+        const v2f tx = __builtin_elementwise_fma((v2f){ (float)((ex >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu) }, sx2, ax2);
+        const v2f ty = __builtin_elementwise_fma((v2f){ (float)((ey >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu) }, sy2, ay2);
+        const v2f tz = __builtin_elementwise_fma((v2f){ (float)((ez >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu) }, sz2, az2);
+        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin0));
+        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bt));
+        key[k] = (tn <= tf) ? __float_as_uint(tn) : 0xffffffffu;     // tn >= tmin0 >= 0: bits order like the value
     }
     cswap(key[0], ref[0], key[1], ref[1]);
     cswap(key[2], ref[2], key[3], ref[3]);

@@ -69,7 +69,7 @@ struct rt_ctx {
     rt_scene_stats stats{};
     DevCamera cam{};
     uint32_t stack_need = 0;    // traversal-stack entries the uploaded tree can need
-    int layout = kBvh2;         // node layout the uploaded scene was flattened to
+    int layout = kBvh4q;        // node layout the uploaded scene was flattened to
     int mode() const {
         if (traversal == 1) return kBrute;
         if (traversal == 2 || traversal == 3) return layout;
@@ -246,8 +246,9 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     build_bvh2(boxes.data(), n_tris, bp, br);
     for (const BuildNode& nd : br.nodes)
         if (nd.count > 8) return fail(c, RT_E_TOO_LARGE, "internal: leaf with more than 8 triangles (depth budget exceeded)");
-    // traversal option 3 asks for the 4-wide quantised layout; everything else gets BVH2 (faster today, r01d)
-    int layout = (c->traversal == 3) ? kBvh4q : kBvh2;
+    // traversal option 2 asks for the plain BVH2 layout; everything else gets the 4-wide quantised one (faster on
+    // every measured config since the sign-selected plane test, scripts/cmp_layouts.py)
+    int layout = (c->traversal == 2) ? kBvh2 : kBvh4q;
     const float pad = std::ldexp(std::max(maxabs, 1e-30f), -c->pad_log2);
     struct { std::vector<float> nodes; std::vector<uint32_t> tri_order; uint32_t n_nodes = 0, n_leaves = 0, depth = 0, stack_need = 0; } flat;
     if (layout == kBvh4q) {
