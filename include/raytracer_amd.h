@@ -54,9 +54,9 @@ enum {
     RT_OPT_COUNTERS = 3,    /* 1: *_dev closest-hit launches run the instrumented kernel and accumulate rt_counters */
     RT_OPT_PAD_LOG2 = 4,    /* BVH boxes are padded by max|coordinate| * 2^-value (default 15); takes effect at upload */
     RT_OPT_MAX_LEAF = 5,    /* triangles per BVH leaf, 1..8 (default 4); takes effect at upload */
-    RT_OPT_STRIP = 6,       /* ray-buffer kernel: rays owned by one wave (default 512); 0 = one ray per lane, no refill */
-    RT_OPT_REFILL = 7       /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 32),
-                               bits 8.. = lanes holding a leaf before the triangle block runs (default 16) */
+    RT_OPT_STRIP = 6,       /* ray-buffer kernel: rays per chunk a persistent wave draws (default 256); 0 = one ray per lane, no refill */
+    RT_OPT_REFILL = 7       /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 16),
+                               bits 8.. = lanes holding a parked leaf before the triangle block runs (default 24) */
 };
 
 /* Scene / acceleration-structure statistics after rt_scene_upload. */

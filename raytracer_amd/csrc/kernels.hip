@@ -13,6 +13,8 @@
 //   normalize(v) = v / sqrt(dot(v,v));  o + t*d = fma(t,d,o)
 // Division and sqrt are IEEE correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the default).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
 #include "kernels.hpp"
 
 namespace rt {
@@ -339,22 +341,24 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 }
 
 // Ray-buffer closest-hit / any-hit with in-wave refill ("strip" kernel).  Incoherent rays finish at very
-// different times (C3 bounce rays: 30 nodes on average, 65 for the slowest lane of a wave), so a lock-step
-// wave idles most lanes.  Here a wave owns a contiguous strip of `strip` rays; whenever at least `refill`
-// lanes are idle they take the next rays of the strip (rank by mbcnt over the idle ballot: coalesced reads,
-// no atomics), while the other lanes keep their traversal state.  Each lane writes its hit when it finishes.
+// different times (C3 bounce rays: 14 nodes on average, several times that for the slowest lane of a wave), so a
+// lock-step wave idles most lanes.  Here the grid is persistent: a wave draws chunks of `strip` consecutive rays
+// from a global cursor (one atomic per chunk, by lane 0); whenever at least `refill` lanes are idle they take the
+// next rays of the chunk (rank by mbcnt over the idle ballot: coalesced reads), while the other lanes keep their
+// traversal state, and a new chunk is drawn as soon as the current one is handed out, so the only tail is the
+// one at the end of the launch.  Each lane writes its hit when it finishes; results do not depend on the order.
 template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
+                                                        unsigned long long* __restrict__ work /* chunk cursor, 0 at launch */,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                         unsigned long long* counters) {
     extern __shared__ int stack[];
     int* stk = stack + threadIdx.x;
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
-    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    uint64_t cursor = wave * strip;                                   // wave-uniform
-    const uint64_t end = (cursor + strip < n) ? cursor + strip : n;
+    uint64_t cursor = 0, end = 0;                                     // wave-uniform: the chunk being handed out
+    bool more = true;                                                 // wave-uniform: the global cursor is not exhausted
     stk[0] = kDone;
     int node = kDone, sp = 1;
     uint64_t my = 0;
@@ -365,10 +369,20 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     Counters c = { 0, 0, 0, 0 };
     uint32_t n_mine = 0;
     uint32_t w_rounds = 0, w_i = 0, w_t = 0;    // wave-uniform scheduling probes (COUNT builds)
+    int pend = 0;                               // postponed leaf (leaf refs are negative; 0 = none)
     for (;;) {
-        const bool idle = node == kDone;
+        const bool idle = node == kDone && pend == 0;
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
+        if (cursor >= end && more && n_idle >= refill) {
+            unsigned long long c0 = 0;
+            if ((threadIdx.x & 63) == 0) c0 = atomicAdd(work, (unsigned long long)strip);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c0 >> 32));
+            cursor = ((uint64_t)hi << 32) | lo;
+            more = cursor < n;
+            end = more ? ((cursor + strip < n) ? cursor + strip : n) : 0;
+            if (!more) cursor = 0;
+        }
         if (cursor < end && n_idle >= refill) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             const uint64_t cand = cursor + rank;
@@ -395,36 +409,36 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
             }
             cursor += (uint64_t)n_idle;
         }
-        const bool live = node != kDone;
+        const bool live = !(node == kDone && pend == 0);
         if (__ballot(live) == 0ull) {
-            if (cursor >= end) break;
+            if (cursor >= end && !more) break;
             continue;
         }
-        // if-if scheduling: per round every lane does at most ONE interior step and ONE triangle test, so no
-        // lane waits for the slowest lane's whole descent.  The triangle block is skipped (wave-uniform
-        // branch) until at least `tth` lanes hold a leaf or no lane has interior work left.
+        // if-if scheduling with one postponed leaf per lane: per round every lane does at most ONE interior
+        // step and ONE triangle test, so no lane waits for the slowest lane's whole descent.  A lane that
+        // reaches a leaf parks it in `pend` and keeps walking from its stack; the triangle block is skipped
+        // (wave-uniform branch) until at least `tth` lanes hold a parked leaf or no lane can walk any further.
         const bool need_i = node >= 0;
-        const unsigned long long mi = __ballot(need_i);
+        if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); }
         if (need_i) node = bvh_step<MODE, COUNT>(nodes, node, sl, tmin0, b.t, stk, sp, c);
-        const bool need_t = node < 0 && node != kDone;
+        if (node < 0 && node != kDone && pend == 0) { pend = node; --sp; node = stk[sp * kBlock]; }
+        const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);
-        if (COUNT) { ++w_rounds; w_i += __popcll(mi); }
-        if (__popcll(mt) >= tth || mi == 0ull) {
+        if (__popcll(mt) >= tth || __ballot(node >= 0) == 0ull) {
             if (COUNT) w_t += __popcll(mt);
             if (need_t) {
-                const uint32_t ref = ~(uint32_t)node;              // (first << 3) | (remaining - 1)
+                const uint32_t ref = ~(uint32_t)pend;              // (first << 3) | (remaining - 1)
                 const float4* tp = tris + (size_t)(ref >> 3) * 3;
                 float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                 float t, u, v;
                 if (tri_hit(o, d, mk(q0.x, q0.y, q0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), t, u, v))
                     consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
                 if (COUNT) ++c.tris;
-                if (ANY && b.t < tmax) { node = kDone; sp = 1; }
-                else if (ref & 7u) node = (int)~(ref + 7u);          // next triangle of the leaf: first+1, remaining-1
-                else { --sp; node = stk[sp * kBlock]; }
+                if (ANY && b.t < tmax) { node = kDone; pend = 0; sp = 1; }
+                else pend = (ref & 7u) ? (int)~(ref + 7u) : 0;       // next triangle of the leaf: first+1, remaining-1
             }
         }
-        if (live && node == kDone) {
+        if (live && node == kDone && pend == 0) {
             if (ANY) occ[my] = b.t < tmax ? 1 : 0;
             else     hits[my] = pack_hit(b, tmax);
         }
@@ -756,6 +770,17 @@ inline size_t stack_bytes(const DevScene& s, int mode) {
     return mode != kBrute ? (size_t)(s.stack_depth + 2) * kBlock * sizeof(int) : 0;
 }
 inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+inline int num_cus() {                        // of the current device (cached per device id)
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cache[dev].load();
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev].store(v);
+    }
+    return v;
+}
 
 }  // namespace
 
@@ -767,10 +792,18 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
     float4* hits = reinterpret_cast<float4*>(d_hits);
     const int rf = refill & 0xff, tth = refill >> 8;
     if (mode != kBrute && strip >= 64) {
-        // strip kernel: one wave per `strip` rays
-        const uint64_t n_waves = (n + strip - 1) / strip;
-        dim3 g((uint32_t)((n_waves + kBlock / 64 - 1) / (kBlock / 64)));
-#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, stack_bytes(s, M), st, s, d_rays, n, strip, rf, tth, hits, d_occ, d_counters)
+        // strip kernel: persistent waves, as many blocks as the chip holds at once (LDS-limited), never more than
+        // there are chunks.  The chunk cursor is one slot of a ring behind the counters, zeroed on the stream.
+        static std::atomic<uint32_t> seq{0};
+        unsigned long long* work = d_counters + kNumCounters + (seq.fetch_add(1) % kWorkSlots);
+        hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
+        const size_t lds = stack_bytes(s, mode);
+        const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
+        const uint64_t n_chunks = (n + strip - 1) / strip;
+        const uint64_t blocks = std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus());
+        dim3 g((uint32_t)blocks);
+#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true); else RT_LAUNCH(M, true, false); } \
                             else         { if (count) RT_LAUNCH(M, false, true); else RT_LAUNCH(M, false, false); } } while (0)
         if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);

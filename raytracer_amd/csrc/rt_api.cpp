@@ -62,8 +62,8 @@ struct rt_ctx {
     int counters = 0;
     int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2
     int max_leaf = 4;
-    uint32_t strip = 512;       // rays per wave in the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
-    int refill = 32 | (16 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
+    uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
+    int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
     // scene
     bool has_scene = false, has_camera = false;
     rt_scene_stats stats{};
@@ -163,8 +163,8 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
         Replica& r = c->reps[i];
         r.device = d;
         if (hipSetDevice(d) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipMalloc(&r.d_counters, kNumCounters * sizeof(unsigned long long)) != hipSuccess ||
-            hipMemset(r.d_counters, 0, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
+            hipMalloc(&r.d_counters, (kNumCounters + kWorkSlots) * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(r.d_counters, 0, (kNumCounters + kWorkSlots) * sizeof(unsigned long long)) != hipSuccess) {
             rt_destroy(c);
             return RT_E_DEVICE;
         }

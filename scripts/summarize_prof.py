@@ -90,7 +90,8 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
         g = lambda x, fmt="{:.1f}": fmt.format(e[x]) if e.get(x) is not None else "-"
         f.write(f"| `{k}` | {d.get('calls','-')} | {d.get('avg_us',0):.1f} | {d.get('vgpr','-')} | {d.get('lds','-')} | {g('hbm_GBps')} ({g('hbm_pct_of_8TBps')}) | {g('l2_hit_pct')} | {g('valu_busy_pct')} | {g('valu_lane_utilisation_pct')} | {g('mean_waves_per_cu')} ({g('occupancy_pct_of_32_waves')}) | {g('lds_bank_conflict_pct_of_lds_cycles','{:.2f}')} | {g('wave_wait_any_pct')} |\n")
 # what bench.py reads for roofline.traffic
-kt = next((d for k, d in out["kernels"].items() if k.startswith("k_trace<2, false, false>") or k.startswith("k_trace<(rt::TraceMode)2, false, false>")), None)
+cands = [d for k, d in out["kernels"].items() if k.startswith("k_trace") and "hbm_bytes" in d.get("derived", {})]
+kt = max(cands, key=lambda d: d.get("total_ms", 0.0)) if cands else None     # the bounce closest-hit launch
 if kt and "hbm_bytes" in kt.get("derived", {}):
     json.dump({"tag": tag, "k_trace_hbm_bytes_per_launch": kt["derived"]["hbm_bytes"]},
               open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"))

@@ -4,7 +4,7 @@ import torch, numpy as np
 import raytracer_amd as rt
 from raytracer_amd import scenes
 tris, sph, _, cam = scenes.sponza_class()
-r = rt.Renderer((0,)); r.set_option(rt.OPT_TRAVERSAL, 2); r.create_data(tris, sph); r.update_camera(cam)
+r = rt.Renderer((0,)); r.set_option(rt.OPT_TRAVERSAL, int(sys.argv[1]) if len(sys.argv) > 1 else rt.TRAVERSAL_BVH); r.create_data(tris, sph); r.update_camera(cam)
 W,H,SPP=3840,2160,4; n=W*H*SPP
 f=lambda k: torch.empty(n*k, dtype=torch.float32, device='cuda')
 rays,hits,brays,bhits,ref=f(8),f(4),f(8),f(4),f(4)
@@ -18,9 +18,9 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/reps
 print("plain k_trace: %.3f ms" % timeit(lambda: r.trace_dev(brays,n,bhits)))
-for strip in (512, 1024, 2048):
-  for tth in (8, 16, 24):
-    for refill in (8, 16, 24, 32):
+for strip in (256, 512, 1024):
+  for tth in (8, 16, 24, 32, 40, 48):
+    for refill in (16, 32):
         r.set_option(rt.OPT_STRIP, strip); r.set_option(rt.OPT_REFILL, refill | (tth << 8))
         ms = timeit(lambda: r.trace_dev(brays,n,bhits))
         ok = torch.equal(bhits.view(torch.int32), ref.view(torch.int32))
