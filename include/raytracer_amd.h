@@ -55,8 +55,12 @@ enum {
     RT_OPT_PAD_LOG2 = 4,    /* BVH boxes are padded by max|coordinate| * 2^-value (default 15); takes effect at upload */
     RT_OPT_MAX_LEAF = 5,    /* triangles per BVH leaf, 1..8 (default 4); takes effect at upload */
     RT_OPT_STRIP = 6,       /* ray-buffer kernel: rays per chunk a persistent wave draws (default 256); 0 = one ray per lane, no refill */
-    RT_OPT_REFILL = 7       /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 16),
+    RT_OPT_REFILL = 7,      /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 16),
                                bits 8.. = lanes holding a parked leaf before the triangle block runs (default 24) */
+    RT_OPT_RAY_BINNING = 8  /* ray-buffer kernel: hand rays out grouped by origin cell (16^3 Morton grid over the scene,
+                               dead rays last): 0 off, 1 on, 2 auto = when nodes + triangles exceed 48 MB and the buffer
+                               holds >= 2^18 rays (default).  Output order and values are unaffected.  Uses per-slot
+                               scratch (4 B per ray): calls on one slot that bin must be stream-ordered. */
 };
 
 /* Scene / acceleration-structure statistics after rt_scene_upload. */
@@ -202,6 +206,15 @@ void     rt_gen_random_rays(uint64_t seed, uint64_t first, uint64_t n, rt_ray* o
  * Camera::updateCameraVectors (src/application/Camera.h:36-41). */
 void     rt_camera_look_at(const float pos[3], const float look_at[3], float fov_deg, float aspect,
                            void* camera_ubo112);
+
+/* minimal Wavefront OBJ reader -> the reference's 144-B Triangle records (src/math/Triangle.h),
+ * ready for rt_scene_upload.  The reference has no loader (its geometry is the literal scene of
+ * src/vulkan/VkRenderer.cpp:164-258 and Sphere::sphereGeometry); BASELINE's configs name real meshes.
+ * Reads `v`, `vn`, `f` (polygons as fans; `a`, `a/b`, `a//c`, `a/b/c`; negative indices); faces without normals get
+ * the geometric normal; every triangle gets `material48` (the reference's 48-B Material; NULL = grey, roughness 0.5).
+ * Writes at most `cap` triangles, always reports the file's triangle count (call with tris144 = NULL to size).
+ * RT_E_INVALID: unreadable file, malformed record or index out of range. */
+int      rt_load_obj(const char* path, const void* material48, void* tris144, uint64_t cap, uint64_t* n_tris_out);
 
 #ifdef __cplusplus
 }

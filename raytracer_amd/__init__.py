@@ -7,6 +7,7 @@ Errors follow the reference's convention (std::runtime_error caught in main, src
 any non-zero ABI return raises RuntimeError(rt_last_error()).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -37,7 +38,7 @@ RAY = np.dtype([("o", "3f4"), ("tmin", "f4"), ("d", "3f4"), ("tmax", "f4")])
 HIT = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("prim", "u4")])
 assert RAY.itemsize == 32 and HIT.itemsize == 16
 
-OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL = 1, 2, 3, 4, 5, 6, 7
+OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING = 1, 2, 3, 4, 5, 6, 7, 8
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
 TRAVERSAL_BVH = TRAVERSAL_BVH4Q
 
@@ -74,6 +75,22 @@ def camera_look_at(pos, look_at, fov_deg, aspect):
     l = (C.c_float * 3)(*look_at)
     lib().rt_camera_look_at(p, l, C.c_float(fov_deg), C.c_float(aspect), _ptr(ubo))
     return ubo
+
+
+def load_obj(path, material=None):
+    """rt_load_obj: Wavefront OBJ -> TRIANGLE records with one material (a MATERIAL-dtype record or None)."""
+    n = C.c_uint64(0)
+    m = None if material is None else np.ascontiguousarray(material)
+    L = lib()
+    rc = L.rt_load_obj(os.fsencode(path), _ptr(m), None, 0, C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"rt_load_obj({path!r}) failed ({rc})")
+    tris = np.zeros(n.value, dtype=TRIANGLE)
+    if n.value:
+        rc = L.rt_load_obj(os.fsencode(path), _ptr(m), _ptr(tris), n.value, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"rt_load_obj({path!r}) failed ({rc})")
+    return tris
 
 
 def default_camera(aspect=1200.0 / 1000.0):

@@ -60,6 +60,7 @@ SYMBOLS = [
     ("rt_gen_soup", _U32, [_U64, _U32, C.c_float, _P, _U32]),
     ("rt_gen_random_rays", None, [_U64, _U64, _U64, _P]),
     ("rt_camera_look_at", None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
+    ("rt_load_obj", _I, [C.c_char_p, _P, _P, _U64, C.POINTER(_U64)]),
 ]
 
 _lib = None

@@ -351,6 +351,7 @@ template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
                                                         unsigned long long* __restrict__ work /* chunk cursor, 0 at launch */,
+                                                        const uint32_t* __restrict__ perm /* hand-out order or null */,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                         unsigned long long* counters) {
     extern __shared__ int stack[];
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             const uint64_t cand = cursor + rank;
             if (idle && cand < end) {
-                my = cand;
+                my = perm ? (uint64_t)perm[cand] : cand;
                 const float4* rp = reinterpret_cast<const float4*>(rays + my);
                 float4 r0 = rp[0], r1 = rp[1];
                 o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
@@ -765,6 +766,79 @@ __global__ __launch_bounds__(kBlock) void k_fill(float4* __restrict__ d, uint64_
     if (i < n) d[i] = v;
 }
 
+// ---- ray binning ------------------------------------------------------------------------------------------
+// Counting sort of ray INDICES by origin cell (kernels.hpp), three launches, no global atomics: per-block
+// histograms -> per-(block, bin) bases -> scatter with LDS cursors.  Rays of one bin keep no particular order.
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4) | ((x & 8u) << 6); }
+__device__ __forceinline__ uint32_t ray_bin(const rt_ray* __restrict__ rays, uint64_t i, const BinGrid& g) {
+    const float4 r0 = reinterpret_cast<const float4*>(rays + i)[0];
+    const float tmax = rays[i].tmax;
+    if (!(tmax > r0.w)) return kBinCells;                                   // dead ray
+    const int x = min(max((int)((r0.x - g.lox) * g.sx), 0), 15);
+    const int y = min(max((int)((r0.y - g.loy) * g.sy), 0), 15);
+    const int z = min(max((int)((r0.z - g.loz) * g.sz), 0), 15);
+    return spread4((uint32_t)x) | (spread4((uint32_t)y) << 1) | (spread4((uint32_t)z) << 2);
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_count(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block,
+                                                      BinGrid g, uint32_t* __restrict__ hist /* [block][kBins] */) {
+    __shared__ uint32_t h[kBins];
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) h[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) atomicAdd(&h[ray_bin(rays, i, g)], 1u);
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * kBins;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) row[b] = h[b];
+}
+
+// hist[block][bin] -> exclusive prefix over blocks (in place); totals[bin] = rays of the bin
+__global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t* __restrict__ totals) {
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= kBins) return;
+    uint32_t run = 0;
+    for (uint32_t k0 = 0; k0 < n_blocks; k0 += 16) {         // 16 independent loads in flight, then the serial prefix
+        uint32_t v[16];
+        #pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) v[j] = (k0 + j < n_blocks) ? hist[(size_t)(k0 + j) * kBins + b] : 0u;
+        #pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            if (k0 + j < n_blocks) hist[(size_t)(k0 + j) * kBins + b] = run;
+            run += v[j];
+        }
+    }
+    totals[b] = run;
+}
+
+// totals[bin] -> start of the bin in the permutation (exclusive scan, one block)
+__global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ totals) {
+    __shared__ uint32_t part[kBlock];
+    constexpr uint32_t per = (kBins + kBlock - 1) / kBlock;
+    const uint32_t lo = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; ++k) if (lo + k < kBins) sum += totals[lo + k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < kBlock; ++k) { const uint32_t v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t k = 0; k < per; ++k) if (lo + k < kBins) { const uint32_t v = totals[lo + k]; totals[lo + k] = run; run += v; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_scatter(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block, BinGrid g,
+                                                        const uint32_t* __restrict__ hist, const uint32_t* __restrict__ starts,
+                                                        uint32_t* __restrict__ perm) {
+    __shared__ uint32_t cur[kBins];
+    const uint32_t* row = hist + (size_t)blockIdx.x * kBins;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) cur[b] = starts[b] + row[b];
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) perm[atomicAdd(&cur[ray_bin(rays, i, g)], 1u)] = (uint32_t)i;
+}
+
 // LDS for the per-lane stacks: sentinel + one entry per BVH level (+1 spare), [entry][thread]
 inline size_t stack_bytes(const DevScene& s, int mode) {
     return mode != kBrute ? (size_t)(s.stack_depth + 2) * kBlock * sizeof(int) : 0;
@@ -784,9 +858,24 @@ inline int num_cus() {                        // of the current device (cached p
 
 }  // namespace
 
+hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (n >= (1ull << 32)) return hipErrorInvalidValue;
+    uint32_t* perm = d_scratch;
+    uint32_t* hist = d_scratch + n;
+    uint32_t* totals = hist + (size_t)kBinBlocksMax * kBins;
+    const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(kBinBlocksMax, (n + 4095) / 4096);
+    const uint64_t per_block = (n + n_blocks - 1) / n_blocks;
+    hipLaunchKernelGGL(k_bin_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, totals);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, perm);
+    return hipGetLastError();
+}
+
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
-                        uint32_t strip, int refill) {
+                        uint32_t strip, int refill, const uint32_t* d_perm) {
     if (n == 0) return hipSuccess;
     dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
@@ -803,7 +892,7 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         const uint64_t n_chunks = (n + strip - 1) / strip;
         const uint64_t blocks = std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus());
         dim3 g((uint32_t)blocks);
-#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, hits, d_occ, d_counters)
+#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true); else RT_LAUNCH(M, true, false); } \
                             else         { if (count) RT_LAUNCH(M, false, true); else RT_LAUNCH(M, false, false); } } while (0)
         if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);

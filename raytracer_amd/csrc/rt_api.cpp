@@ -43,6 +43,8 @@ struct Replica {
     // scratch for host-pointer entry points
     void* d_rays = nullptr;  size_t rays_cap = 0;
     void* d_out = nullptr;   size_t out_cap = 0;
+    // scratch for ray binning (permutation + histograms, uint32 words)
+    uint32_t* d_bin = nullptr; uint64_t bin_cap = 0;
     std::string err;
 };
 
@@ -64,6 +66,8 @@ struct rt_ctx {
     int max_leaf = 4;
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
+    int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
+    BinGrid bin_grid{};         // 16^3 grid over the triangle bounds of the uploaded scene
     // scene
     bool has_scene = false, has_camera = false;
     rt_scene_stats stats{};
@@ -111,6 +115,33 @@ void free_scene(Replica& r) {
     if (r.d_sphere_mat) (void)hipFree(r.d_sphere_mat);
     if (r.d_lights) (void)hipFree(r.d_lights);
     r.d_nodes = r.d_tris = r.d_normals = r.d_spheres = r.d_materials = r.d_sphere_mat = r.d_lights = nullptr;
+}
+
+// Closest-hit / any-hit over a ray buffer in HBM.  With binning the rays are handed out grouped by origin cell
+// (launch_bin), which keeps a wave's node fetches close together when the structure does not fit the L2s.
+constexpr uint64_t kBinMinRays = 1ull << 18;
+constexpr uint64_t kBinMinSceneBytes = 48ull << 20;
+hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
+                      uint8_t* d_occ, hipStream_t st) {
+    const int mode = c->mode();
+    const uint64_t scene_bytes = (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48;
+    const bool bin = mode != kBrute && c->strip >= 64 && n >= kBinMinRays && n < (1ull << 32) &&
+                     (c->binning == 1 || (c->binning == 2 && scene_bytes > kBinMinSceneBytes));
+    const uint32_t* perm = nullptr;
+    if (bin) {
+        const uint64_t words = bin_scratch_words(n);
+        if (words > r.bin_cap) {
+            if (r.d_bin) (void)hipFree(r.d_bin);
+            r.d_bin = nullptr; r.bin_cap = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&r.d_bin), words * sizeof(uint32_t));
+            if (e != hipSuccess) return e;
+            r.bin_cap = words;
+        }
+        hipError_t e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, st);
+        if (e != hipSuccess) return e;
+        perm = r.d_bin;
+    }
+    return launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm);
 }
 
 bool valid_slot(const rt_ctx* c, int slot) { return c && slot >= 0 && slot < (int)c->reps.size(); }
@@ -182,6 +213,7 @@ void rt_destroy(rt_ctx* c) {
         if (r.d_counters) (void)hipFree(r.d_counters);
         if (r.d_rays) (void)hipFree(r.d_rays);
         if (r.d_out) (void)hipFree(r.d_out);
+        if (r.d_bin) (void)hipFree(r.d_bin);
         if (r.d_render) (void)hipFree(r.d_render);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
@@ -199,6 +231,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) {
         case RT_OPT_TRAVERSAL:   if (v < 0 || v > 3) return fail(c, RT_E_INVALID, "RT_OPT_TRAVERSAL: 0 auto, 1 brute, 2 BVH2, 3 BVH4q"); c->traversal = (int)v; return RT_OK;
         case RT_OPT_BVH_THREADS: if (v < 0 || v > 256) return fail(c, RT_E_INVALID, "RT_OPT_BVH_THREADS out of range"); c->bvh_threads = (int)v; return RT_OK;
         case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
+        case RT_OPT_RAY_BINNING: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_RAY_BINNING: 0 off, 1 on, 2 auto"); c->binning = (int)v; return RT_OK;
         case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
         case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;
         case RT_OPT_STRIP:       if (v != 0 && (v < 64 || v > (1 << 24))) return fail(c, RT_E_INVALID, "RT_OPT_STRIP: 0 or 64..2^24"); c->strip = (uint32_t)v; return RT_OK;
@@ -223,6 +256,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     std::vector<Aabb> boxes(n_tris);
     float maxabs = 0.f;
     const char* tb = static_cast<const char*>(tris);
+    Aabb scene_box; scene_box.reset();
     for (uint32_t i = 0; i < n_tris; ++i) {
         const char* t = tb + (size_t)i * tri_stride;
         Aabb b; b.reset();
@@ -236,6 +270,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
             b.grow(p);
         }
         boxes[i] = b;
+        scene_box.grow(b);
     }
     // 2. BVH2 build + flatten
     BuildParams bp;
@@ -353,6 +388,14 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     st.n_tris = n_tris; st.n_spheres = n_spheres; st.n_lights = n_lights;
     st.n_nodes = flat.n_nodes; st.n_leaves = flat.n_leaves; st.max_depth = flat.depth;
     c->stack_need = flat.stack_need; c->layout = layout;
+    {
+        float* lo = &c->bin_grid.lox; float* sc = &c->bin_grid.sx;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = n_tris ? scene_box.hi[a] - scene_box.lo[a] : 0.f;
+            lo[a] = n_tris ? scene_box.lo[a] : 0.f;
+            sc[a] = ext > 0.f ? 16.0f / ext : 0.f;
+        }
+    }
     st.node_bytes = 64; st.tri_bytes = 48;
     st.sah_cost = br.sah_cost;
     st.build_ms = (float)(t1 - t0); st.upload_ms = (float)(t2 - t1);
@@ -479,7 +522,7 @@ int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* 
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
-    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), false, c->counters != 0, d_rays, n, d_hits, nullptr, r.d_counters, st, c->strip, c->refill));
+    RT_HIP(c, trace_rays(c, r, false, c->counters != 0, d_rays, n, d_hits, nullptr, st));
     return RT_OK;
 }
 
@@ -490,7 +533,7 @@ int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
-    RT_HIP(c, launch_trace(c->dev_scene(r), c->mode(), true, false, d_rays, n, nullptr, d_out, r.d_counters, st, c->strip, c->refill));
+    RT_HIP(c, trace_rays(c, r, true, false, d_rays, n, nullptr, d_out, st));
     return RT_OK;
 }
 
@@ -600,7 +643,7 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         for (uint32_t b = 0; b < bounces; ++b) {
             RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, 0, 1, 1, seed + 1u + b, thr, rad, b + 1 < bounces ? rb : nullptr, r.stream));
             if (b + 1 < bounces)
-                RT_HIP_SLOT(r, launch_trace(ds, mode, false, false, rb, n, hits, nullptr, r.d_counters, r.stream, c->strip, c->refill));
+                RT_HIP_SLOT(r, trace_rays(c, r, false, false, rb, n, hits, nullptr, r.stream));
             std::swap(ra, rb);
         }
         RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));
@@ -676,7 +719,6 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
     const int ns = (int)c->reps.size();
     const uint64_t per = (n + ns - 1) / ns;
     const size_t osz = any_hit ? 1 : sizeof(rt_hit);
-    const int mode = c->mode();
     return for_each_slot(c, [&](int s) -> int {
         Replica& r = c->reps[s];
         const uint64_t b = std::min(per * s, n), e = std::min(b + per, n);
@@ -698,9 +740,9 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
         for (uint64_t i = b; i < e; i += chunk) {
             const uint64_t m = std::min(chunk, e - i);
             RT_HIP_SLOT(r, hipMemcpyAsync(r.d_rays, rays + i, m * sizeof(rt_ray), hipMemcpyHostToDevice, r.stream));
-            RT_HIP_SLOT(r, launch_trace(c->dev_scene(r), mode, any_hit, false, static_cast<const rt_ray*>(r.d_rays), m,
-                                        any_hit ? nullptr : static_cast<rt_hit*>(r.d_out),
-                                        any_hit ? static_cast<uint8_t*>(r.d_out) : nullptr, r.d_counters, r.stream, c->strip, c->refill));
+            RT_HIP_SLOT(r, trace_rays(c, r, any_hit, false, static_cast<const rt_ray*>(r.d_rays), m,
+                                      any_hit ? nullptr : static_cast<rt_hit*>(r.d_out),
+                                      any_hit ? static_cast<uint8_t*>(r.d_out) : nullptr, r.stream));
             RT_HIP_SLOT(r, hipMemcpyAsync(static_cast<char*>(out) + i * osz, r.d_out, m * osz, hipMemcpyDeviceToHost, r.stream));
             RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
         }

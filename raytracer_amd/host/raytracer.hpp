@@ -38,6 +38,19 @@ public:
     void tracePrimary(uint32_t w, uint32_t h, rt_hit* out) { check(rt_trace_primary(ctx_, w, h, out)); }
     void trace(const rt_ray* rays, uint64_t n, rt_hit* out) { check(rt_trace(ctx_, rays, n, out)); }
     void occluded(const rt_ray* rays, uint64_t n, uint8_t* out) { check(rt_occluded(ctx_, rays, n, out)); }
+    // the draw, whole shader (frag.glsl:303-360): spp x bounces path loop -> RGBA8, row 0 = top
+    void render(uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* rgba8) {
+        check(rt_render(ctx_, w, h, spp, bounces, seed, rgba8));
+    }
+    // Wavefront OBJ -> Triangle records with one material
+    static std::vector<Triangle> loadObj(const std::string& path, const Material* material = nullptr) {
+        uint64_t n = 0;
+        int rc = rt_load_obj(path.c_str(), material, nullptr, 0, &n);
+        std::vector<Triangle> t(n);
+        if (rc == RT_OK && n) rc = rt_load_obj(path.c_str(), material, t.data(), n, &n);
+        if (rc != RT_OK) throw std::runtime_error("rt_load_obj failed for " + path + " (code " + std::to_string(rc) + ")");
+        return t;
+    }
     void setOption(int key, int64_t v) { check(rt_set_option(ctx_, key, v)); }
     rt_scene_stats stats() const { rt_scene_stats s; check(rt_scene_stats_get(ctx_, &s)); return s; }
     rt_ctx* raw() { return ctx_; }

@@ -3,7 +3,11 @@
 // Cornell scene and default camera, traces one frame of primary rays through the C ABI and writes a PPM
 // that visualises the hit buffer (primitive id + distance).  Error handling mirrors src/main.cpp:5-17.
 //
-// usage: rt_headless [width height [out.ppm]]
+// With spp and bounces it runs the whole shader instead (rt_render, frag.glsl:303-360) and writes the RGBA8 frame --
+// the headless form of the presentation hook.  A Wavefront OBJ can replace the three
+// Cornell spheres.
+//
+// usage: rt_headless [width height [out.ppm [spp bounces [mesh.obj]]]]
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -23,6 +27,12 @@ int main(int argc, char** argv) {
         std::vector<rt::Sphere> spheres(rt_gen_cornell_spheres(nullptr, 0));
         rt_gen_cornell_spheres(spheres.data(), (uint32_t)spheres.size());
         std::vector<rt::Light> lights;                                         // VkRenderer.cpp:252-258: none
+        const uint32_t spp = argc > 5 ? (uint32_t)std::atoi(argv[4]) : 0, bounces = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 0;
+        if (argc > 6) {                                                        // mesh instead of the spheres
+            const std::vector<rt::Triangle> mesh = rt::Engine::loadObj(argv[6]);
+            tris.insert(tris.end(), mesh.begin(), mesh.end());
+            spheres.clear();
+        }
 
         rt::Engine engine({0});
         engine.upload(tris, spheres, lights);
@@ -31,12 +41,23 @@ int main(int argc, char** argv) {
         rt_camera_look_at(pos, look, 45.0f, (float)w / (float)h, &cam);
         engine.setCamera(&cam);
 
-        std::vector<rt_hit> hits((size_t)w * h);
-        engine.tracePrimary(w, h, hits.data());
-
         std::ofstream f(path, std::ios::binary);
         if (!f) throw std::runtime_error(std::string("failed to open ") + path);
         f << "P6\n" << w << " " << h << "\n255\n";
+        if (spp) {
+            std::vector<uint8_t> frame((size_t)w * h * 4);
+            engine.render(w, h, spp, bounces, 1u, frame.data());
+            size_t lit = 0;
+            for (size_t p = 0; p < (size_t)w * h; ++p) {
+                f.write(reinterpret_cast<const char*>(&frame[4 * p]), 3);
+                lit += (frame[4 * p] | frame[4 * p + 1] | frame[4 * p + 2]) != 0;
+            }
+            std::cout << "rendered " << w << "x" << h << " at " << spp << " spp, " << bounces << " bounces, " << lit
+                      << " non-black pixels, " << engine.stats().n_tris << " triangles -> " << path << std::endl;
+            return EXIT_SUCCESS;
+        }
+        std::vector<rt_hit> hits((size_t)w * h);
+        engine.tracePrimary(w, h, hits.data());
         size_t n_hit = 0;
         for (const rt_hit& hit : hits) {
             unsigned char rgb[3] = {0, 0, 0};

@@ -1,16 +1,17 @@
 #!/bin/bash
 # Collects rocprofv3 PMC counters for the bench workload, one pass per run (gfx950 slot limits:
 # 8 SQ, 4 TCC, 4 TCP, 2 TA, 2 GRBM per pass; FETCH_SIZE = 3 TCC, WRITE_SIZE = 2 TCC).
-# usage: scripts/pmc_passes.sh <outdir> [bench args...]
+# usage: [RT_PMC_PROG=scripts/c4_prof.py] scripts/pmc_passes.sh <outdir> [program args...]
 set -o pipefail
 OUT=${1:-gpurun_out/pmc}; shift
 ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline}
+PROG=${RT_PMC_PROG:-bench.py}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p "$OUT"
 pass() {
   local name=$1; shift
   echo "== pass $name: $*"
-  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $PROG $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
 }
 pass fetch FETCH_SIZE &&
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum &&

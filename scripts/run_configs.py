@@ -128,6 +128,20 @@ def c4(n_tris, n_rays):
                                           "prim_id_mismatches_bvh2": int((b["prim"] != keep["bvh2"][:m]["prim"]).sum()),
                                           "bit_exact_bvh2": bool(b.tobytes() == keep["bvh2"][:m].tobytes())}
                 keep["brute"] = b
+    # default path (BVH4q + ray binning) and the PCIe-inclusive rate of the host-pointer entry point
+    with rt.Renderer((0,)) as r:
+        r.create_data(tris)
+        for name, b in (("bvh4q_binned", 1), ("bvh4q_unbinned", 0)):
+            r.set_option(rt.OPT_RAY_BINNING, b)
+            ms = timeit(lambda: r.trace_dev(rays, n_rays, hits), 3)
+            res[name] = {"ms": round(ms, 3), "Mrays_s": round(n_rays / ms / 1e3, 1),
+                         "same_as_bvh2": bool(hits.cpu().numpy().view(rt.HIT).tobytes() == keep["bvh2"].tobytes())}
+        r.set_option(rt.OPT_RAY_BINNING, 2)
+        mh = min(n_rays, 1 << 24)
+        t = time.time(); hh = r.trace(rays_np[:mh]); dt = time.time() - t
+        res["host_ptr"] = {"rays": mh, "seconds": round(dt, 3), "host_ptr_Mrays_s": round(mh / dt / 1e6, 1),
+                           "same": bool(hh.tobytes() == keep["bvh2"][:mh].tobytes()),
+                           "note": "rt_trace: pageable H2D of rays + kernels + D2H of hits, 4 Mi-ray pieces"}
     m = len(keep["brute"])
     res["gpu_brute_check"]["prim_id_mismatches_bvh4q"] = int((keep["brute"]["prim"] != keep["bvh4q"][:m]["prim"]).sum())
     res["layouts_agree"] = bool(keep["bvh2"].tobytes() == keep["bvh4q"].tobytes())
@@ -143,7 +157,7 @@ def c5(n_tris):
     cam = rt.camera_look_at((0.5, 2.2, 0.5), (0.5, 0.5, 0.5), 45.0, w / h)
     n = w * h * spp
     with rt.Renderer((0,)) as r:
-        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH2)
+        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
         r.create_data(tris); r.update_camera(cam)
         ra, rb, hits, thr, rad = f32(n * 8), f32(n * 8), f32(n * 4), f32(n * 4), f32(n * 4)
         fb = torch.empty(w * h, dtype=torch.int32, device=dev)

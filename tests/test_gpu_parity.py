@@ -243,6 +243,34 @@ def test_soup_bvh_and_brute_vs_oracle(renderer, n_tris, half, n_rays, leaf):
         assert np.array_equal(renderer.occluded(rays), (ref["prim"] != rt.MISS).astype(np.uint8))
 
 
+def test_ray_binning_changes_the_order_not_the_answer(renderer, torch_dev):
+    """RT_OPT_RAY_BINNING hands rays out grouped by origin cell; every hit must land in its own slot, bit for bit,
+    including dead rays (tmax <= tmin), rays that start outside the scene bounds, any-hit, and a ragged count."""
+    n = (1 << 18) + 4321
+    st, rays = scenes.soup(30000, half_extent=0.02), scenes.random_rays(n)
+    rays["o"][::7] = rays["o"][::7] * 4 - 2                  # outside the grid: clamped to border cells
+    rays["tmax"][3::11] = 0.05                               # short intervals
+    rays["tmax"][::5] = 0.0                                  # dead rays: their own bin
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(st)
+    d_rays = to_dev(torch_dev, rays)
+    out = {}
+    for binning in (0, 1):
+        renderer.set_option(rt.OPT_RAY_BINNING, binning)
+        hits, occ = dev_buf(torch_dev, n, 16), torch_dev.zeros(n, dtype=torch_dev.uint8, device="cuda")
+        renderer.trace_dev(d_rays, n, hits)
+        renderer.occluded_dev(d_rays, n, occ)
+        torch_dev.cuda.synchronize()
+        out[binning] = (to_np(hits, rt.HIT).copy(), occ.cpu().numpy().copy())
+    assert out[0][0].tobytes() == out[1][0].tobytes()
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    assert (out[1][0]["prim"][::5] == rt.MISS).all() and (out[1][0]["prim"] != rt.MISS).any()
+    idx = np.sort(np.random.default_rng(3).choice(n, 4096, replace=False))
+    assert_parity(out[1][0][idx], oracle.trace(oracle.Scene(st), rays[idx]), "binned soup sample vs oracle")
+    # the host-pointer entry point goes through the same path (4 Mi-ray pieces)
+    assert renderer.trace(rays).tobytes() == out[0][0].tobytes()
+
+
 def test_two_slots_on_one_device_equal_one_slot():
     st, rays = scenes.soup(5000, half_extent=0.05), scenes.random_rays(10001)
     tris, sph, _ = scenes.cornell()
@@ -391,6 +419,17 @@ def test_cpp_headless_harness(tmp_path):
     assert "3072 hits" in p.stdout and "12 triangles" in p.stdout
     data = out.read_bytes()
     assert data.startswith(b"P6\n64 48\n255\n") and len(data) == len(b"P6\n64 48\n255\n") + 64 * 48 * 3
+    # whole shader (rt_render) + an OBJ mesh in place of the spheres: the headless presentation hook (f2, f3)
+    obj = tmp_path / "tet.obj"
+    obj.write_text("v -0.5 0.2 0.5\nv 0.5 0.2 0.5\nv 0 0.2 1.5\nv 0 1.0 1.0\nf 1 2 4\nf 2 3 4\nf 3 1 4\nf 1 3 2\n")
+    p = subprocess.run([exe, "64", "48", str(out), "2", "2", str(obj)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "rendered 64x48 at 2 spp, 2 bounces" in p.stdout and "16 triangles" in p.stdout
+    lit = int(p.stdout.split(" non-black")[0].split()[-1])
+    assert lit > 64 * 48 // 4
+    assert len(out.read_bytes()) == len(b"P6\n64 48\n255\n") + 64 * 48 * 3
+    p = subprocess.run([exe, "64", "48", str(out), "2", "2", str(tmp_path / "missing.obj")], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "rt_load_obj failed" in p.stderr
     p = subprocess.run([exe, "0", "0", str(out)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 1 and "empty image" in p.stderr          # EXIT_FAILURE + message, as src/main.cpp:8-14
 
