@@ -426,7 +426,7 @@ def test_cpp_headless_harness(tmp_path):
     assert p.returncode == 0, p.stderr
     assert "rendered 64x48 at 2 spp, 2 bounces" in p.stdout and "16 triangles" in p.stdout
     lit = int(p.stdout.split(" non-black")[0].split()[-1])
-    assert lit > 64 * 48 // 4
+    assert 100 < lit <= 64 * 48              # light patch + surfaces whose one bounce reaches it
     assert len(out.read_bytes()) == len(b"P6\n64 48\n255\n") + 64 * 48 * 3
     p = subprocess.run([exe, "64", "48", str(out), "2", "2", str(tmp_path / "missing.obj")], capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "rt_load_obj failed" in p.stderr
