@@ -352,12 +352,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
                                                         uint32_t strip, int refill, int tth,
                                                         unsigned long long* __restrict__ work /* chunk cursor, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
+                                                        const uint32_t* __restrict__ perm_on /* device flag, null = on */,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                         unsigned long long* counters) {
     extern __shared__ int stack[];
     int* stk = stack + threadIdx.x;
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
+    if (perm && perm_on && *perm_on == 0u) perm = nullptr;             // launch_bin found the buffer coherent already
     uint64_t cursor = 0, end = 0;                                     // wave-uniform: the chunk being handed out
     bool more = true;                                                 // wave-uniform: the global cursor is not exhausted
     stk[0] = kDone;
@@ -793,10 +795,11 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const rt_ray* __restrict__
 }
 
 // hist[block][bin] -> exclusive prefix over blocks (in place); totals[bin] = rays of the bin
-__global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t* __restrict__ totals) {
+__global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t* __restrict__ totals,
+                                                        uint32_t* __restrict__ meta /* [1] += non-empty (block, bin) pairs */) {
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= kBins) return;
-    uint32_t run = 0;
+    uint32_t run = 0, pairs = 0;
     for (uint32_t k0 = 0; k0 < n_blocks; k0 += 16) {         // 16 independent loads in flight, then the serial prefix
         uint32_t v[16];
         #pragma unroll
@@ -805,13 +808,16 @@ __global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ h
         for (uint32_t j = 0; j < 16; ++j) {
             if (k0 + j < n_blocks) hist[(size_t)(k0 + j) * kBins + b] = run;
             run += v[j];
+            pairs += v[j] != 0u;
         }
     }
     totals[b] = run;
+    if (pairs) atomicAdd(&meta[1], pairs);
 }
 
 // totals[bin] -> start of the bin in the permutation (exclusive scan, one block)
-__global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ totals) {
+__global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ totals, uint32_t* __restrict__ meta, uint64_t n, uint32_t min_run) {
+    if (threadIdx.x == 0) meta[0] = (min_run == 0u || n < (uint64_t)min_run * meta[1]) ? 1u : 0u;   // permute?
     __shared__ uint32_t part[kBlock];
     constexpr uint32_t per = (kBins + kBlock - 1) / kBlock;
     const uint32_t lo = threadIdx.x * per;
@@ -830,8 +836,9 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ tota
 
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block, BinGrid g,
                                                         const uint32_t* __restrict__ hist, const uint32_t* __restrict__ starts,
-                                                        uint32_t* __restrict__ perm) {
+                                                        const uint32_t* __restrict__ meta, uint32_t* __restrict__ perm) {
     __shared__ uint32_t cur[kBins];
+    if (meta[0] == 0u) return;                                               // coherent input: keep its order
     const uint32_t* row = hist + (size_t)blockIdx.x * kBins;
     for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) cur[b] = starts[b] + row[b];
     __syncthreads();
@@ -858,24 +865,27 @@ inline int num_cus() {                        // of the current device (cached p
 
 }  // namespace
 
-hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, hipStream_t st) {
+hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st) {
     if (n == 0) return hipSuccess;
     if (n >= (1ull << 32)) return hipErrorInvalidValue;
     uint32_t* perm = d_scratch;
     uint32_t* hist = d_scratch + n;
     uint32_t* totals = hist + (size_t)kBinBlocksMax * kBins;
+    uint32_t* meta = totals + kBins;                 // [0] permute flag, [1] non-empty (block, bin) pairs
     const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(kBinBlocksMax, (n + 4095) / 4096);
     const uint64_t per_block = (n + n_blocks - 1) / n_blocks;
+    hipError_t e = hipMemsetAsync(meta, 0, 4 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bin_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist);
-    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, totals);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, perm);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, totals, meta);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, meta, n, min_run);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, meta, perm);
     return hipGetLastError();
 }
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
-                        uint32_t strip, int refill, const uint32_t* d_perm) {
+                        uint32_t strip, int refill, const uint32_t* d_perm, const uint32_t* d_perm_on) {
     if (n == 0) return hipSuccess;
     dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
@@ -892,7 +902,7 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         const uint64_t n_chunks = (n + strip - 1) / strip;
         const uint64_t blocks = std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus());
         dim3 g((uint32_t)blocks);
-#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, hits, d_occ, d_counters)
+#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true); else RT_LAUNCH(M, true, false); } \
                             else         { if (count) RT_LAUNCH(M, false, true); else RT_LAUNCH(M, false, false); } } while (0)
         if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);

@@ -36,14 +36,19 @@ constexpr uint32_t kBins = kBinCells + 1;
 constexpr uint32_t kBinBlocksMax = 1024;
 struct BinGrid { float lox, loy, loz, sx, sy, sz; };        // cell = clamp((o - lo) * s, 0, 15)
 // scratch words (uint32) that launch_bin needs for n rays: the permutation + per-block histograms
-inline uint64_t bin_scratch_words(uint64_t n) { return n + (uint64_t)kBinBlocksMax * kBins + kBins; }
+inline uint64_t bin_scratch_words(uint64_t n) { return n + (uint64_t)kBinBlocksMax * kBins + kBins + 4; }
+// word 0 behind the bin totals: 1 if the permutation is to be used (see launch_bin), 0 if the input was coherent already
+inline const uint32_t* bin_flag(const uint32_t* d_scratch, uint64_t n) { return d_scratch + n + (uint64_t)kBinBlocksMax * kBins + kBins; }
 // d_scratch[0 .. n) receives the permutation (ray indices grouped by bin); n must be < 2^32
-hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, hipStream_t st);
+// min_run: the rays are only permuted when a (64 Ki-ray block, cell) pair holds fewer than min_run rays on average,
+// i.e. when the buffer is not grouped by origin already (0 = always permute).  The decision is taken on the device.
+hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st);
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
                         uint32_t strip /* rays per chunk, 0 = one ray per lane */, int refill /* idle lanes that trigger a refill */,
-                        const uint32_t* d_perm = nullptr /* order in which rays are handed out (strip kernel only) */);
+                        const uint32_t* d_perm = nullptr /* order in which rays are handed out (strip kernel only) */,
+                        const uint32_t* d_perm_on = nullptr /* device flag: 0 = ignore d_perm */);
 
 hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, bool count, uint32_t w, uint32_t h,
                           uint32_t y0, uint32_t rows, uint32_t stripe_h, uint32_t stripe_step, uint32_t spp,

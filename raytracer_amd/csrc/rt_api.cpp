@@ -121,6 +121,7 @@ void free_scene(Replica& r) {
 // (launch_bin), which keeps a wave's node fetches close together when the structure does not fit the L2s.
 constexpr uint64_t kBinMinRays = 1ull << 18;
 constexpr uint64_t kBinMinSceneBytes = 48ull << 20;
+constexpr uint32_t kBinMinRun = 128;      // mean rays per non-empty (64 Ki-ray block, cell) pair above which a buffer counts as coherent
 hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
                       uint8_t* d_occ, hipStream_t st) {
     const int mode = c->mode();
@@ -137,11 +138,13 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
             if (e != hipSuccess) return e;
             r.bin_cap = words;
         }
-        hipError_t e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, st);
+        // auto: permute only buffers that are not grouped by origin already (camera-ordered bounce rays are)
+        hipError_t e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, c->binning == 1 ? 0u : kBinMinRun, st);
         if (e != hipSuccess) return e;
         perm = r.d_bin;
     }
-    return launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm);
+    return launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm,
+                        perm ? bin_flag(perm, n) : nullptr);
 }
 
 bool valid_slot(const rt_ctx* c, int slot) { return c && slot >= 0 && slot < (int)c->reps.size(); }
