@@ -10,5 +10,5 @@ import json
 d=json.loads(open('gpurun_out/bench_cycle.json').read().strip().splitlines()[-1])
 print("value", d["value"], "Mrays/s  ms/step", d["ms_per_step"])
 print("kernels", d["kernels"])
-print("roofline", d["roofline"]["frac"], d["roofline"]["work_per_ray"], "valu", d["roofline_valu"]["frac"])
+print("roofline", d["roofline"]["frac"], d["roofline"]["work_per_ray"], "hbm-form", d["roofline_hbm"]["frac"])
 PY
