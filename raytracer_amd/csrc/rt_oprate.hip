@@ -1,0 +1,54 @@
+// rt_oprate.hip -- issue cost of the VALU instruction classes the traversal step is made of (one dependent chain of 8 per lane,
+// 8 waves per SIMD): tells which instructions are full-rate and which quarter-rate on gfx950.  Standalone, like rt_peaks.hip.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+// 8 independent chains, each step one instruction of the given kind
+#define KERNEL(NAME, ASM, ...) \
+__global__ __launch_bounds__(256) void NAME(float* out, float a, float b) { \
+    float x[8]; \
+    for (int k = 0; k < 8; ++k) x[k] = (float)(threadIdx.x + k) * a; \
+    for (int it = 0; it < 4096; ++it) { \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile(ASM : "+v"(x[k]) : __VA_ARGS__); \
+    } \
+    float s = 0.f; for (int k = 0; k < 8; ++k) s += x[k]; \
+    if (s == 12345.678f) out[0] = s; }
+KERNEL(k_fma,    "v_fma_f32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_mul,    "v_mul_f32 %0, %0, %1", "v"(a))
+KERNEL(k_add,    "v_add_f32 %0, %0, %1", "v"(a))
+KERNEL(k_min,    "v_min_f32 %0, %0, %1", "v"(a))
+KERNEL(k_max3,   "v_max3_f32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_cvtub,  "v_cvt_f32_ubyte1 %0, %0", "v"(a))
+KERNEL(k_cvtu,   "v_cvt_f32_u32 %0, %0", "v"(a))
+KERNEL(k_and,    "v_and_b32 %0, %0, %1", "v"(a))
+KERNEL(k_addu,   "v_add_u32 %0, %0, %1", "v"(a))
+KERNEL(k_minu,   "v_min_u32 %0, %0, %1", "v"(a))
+KERNEL(k_lshl,   "v_lshlrev_b32 %0, 1, %0", "v"(a))
+KERNEL(k_cndm,   "v_cndmask_b32 %0, %0, %1, vcc", "v"(a))
+KERNEL(k_bfe,    "v_bfe_u32 %0, %0, 8, 8", "v"(a))
+KERNEL(k_perm,   "v_perm_b32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_mov,    "v_mov_b32 %0, %0", "v"(a))
+KERNEL(k_rcp,    "v_rcp_f32 %0, %0", "v"(a))
+KERNEL(k_cmp,    "v_cmp_lt_f32 vcc, %0, %1", "v"(a))
+KERNEL(k_cvtpk,  "v_cvt_pkrtz_f16_f32 %0, %0, %1", "v"(a))
+KERNEL(k_sdwa,   "v_cvt_f32_ubyte0_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2", "v"(a))
+typedef void (*kfn)(float*, float, float);
+int main() {
+    float* out; CHECK(hipMalloc(&out, 64));
+    int cus = 0; CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    struct { const char* n; kfn f; } ks[] = { {"v_fma_f32", k_fma}, {"v_mul_f32", k_mul}, {"v_add_f32", k_add}, {"v_min_f32", k_min}, {"v_max3_f32", k_max3},
+        {"v_cvt_f32_ubyte1", k_cvtub}, {"v_cvt_f32_u32", k_cvtu}, {"v_and_b32", k_and}, {"v_add_u32", k_addu}, {"v_min_u32", k_minu}, {"v_lshlrev_b32", k_lshl},
+        {"v_cndmask_b32", k_cndm}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_cmp_lt_f32", k_cmp}, {"v_cvt_pkrtz", k_cvtpk}, {"cvt_ubyte_sdwa", k_sdwa} };
+    const int grid = cus * 32;
+    for (auto& k : ks) {
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k.f, dim3(grid), dim3(256), 0, 0, out, 1.0001f, 0.5f); CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0, 0));
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k.f, dim3(grid), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+        double wi = (double)grid * 4 * 8.0 * 4096;
+        std::printf("%-20s %.4f instr/SIMD-cycle  (%.2f cycles per wave64 instr)\n", k.n, wi / (ms * 1e-3) / (cus * 4.0 * 2.4e9), (cus * 4.0 * 2.4e9) * (ms * 1e-3) / wi);
+    }
+    return 0;
+}
