@@ -5,11 +5,12 @@ Workload (config.workload): C3 of BASELINE.md -- the "Sponza-class" scene the no
 cannot be fetched, so the scene is the labelled procedural stand-in of SURVEY.md 8(d): 8 x 8
 sphereGeometry(45,45) in a closed room = 259,212 triangles.  One step = one 3840x2160 frame at 4 spp,
 every stage on device, nothing skipped:
-  1. k_primary      jittered primary rays generated on device + closest hit    (33.2 M rays, coherent)
-  2. k_shade        emission + Cook-Torrance throughput + cosine-weighted bounce ray (frag.glsl:310-350)
-  3. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent)
-  4. k_shade        radiance of the second segment;  k_resolve -> RGBA8 framebuffer (frag.glsl:357-359)
-  5. N > 1 only: all-gather of the per-rank framebuffer stripes over RCCL/xGMI + de-interleave
+  1. k_primary      jittered primary rays generated on device + closest hit    (33.2 M rays, coherent), fused with
+                    segment 0 of the path loop: emission + Cook-Torrance throughput + cosine-weighted bounce ray
+                    (frag.glsl:310-350)
+  2. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent)
+  3. k_shade        radiance of the second segment;  k_resolve -> RGBA8 framebuffer (frag.glsl:357-359)
+  4. N > 1 only: all-gather of the per-rank framebuffer stripes over RCCL/xGMI + de-interleave
 value = closest-hit rays of the whole job / wall time (max over ranks).  With N ranks the frame's 16-row
 stripes are interleaved over the ranks (BVH replicated): total work is fixed, so scaling is "strong".
 
@@ -32,7 +33,7 @@ import raytracer_amd as rt                      # noqa: E402
 from raytracer_amd import dist as rd            # noqa: E402
 from raytracer_amd import scenes                # noqa: E402
 
-W, H, SPP, SEED, STRIPE = 3840, 2160, 4, 1, 16
+W, H, SPP, SEED, STRIPE = 3840, 2160, 4, 1, 8
 # MI355X_MICROARCH.md, chip-level parameters: 157.3 TFLOP/s fp32 vector peak (that figure counts packed
 # v_pk_fma_f32; plain wave64 VALU issues one instruction per 4 cycles per SIMD = 78.6 TFLOP/s of scalar fma),
 # 8 TB/s HBM3E spec (6.29 TB/s measured achievable).
@@ -98,13 +99,16 @@ def main():
     row_len = W * SPP
     key0 = plan.y0 * row_len                                         # RNG key = path index in the full frame
 
-    def stage_primary():
-        r.path_init_dev(n_local, thr, rad, stream=stream)
+    def stage_primary_shade():
+        # primary rays, their closest hits and segment 0 of the path loop in one launch: the primary rays and
+        # hits stay in registers, throughput / radiance / bounce rays are written once
+        r.primary_shade_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, world, thr, rad, brays, spp=SPP, seed=SEED,
+                                    jitter=True, shade_seed=SEED + 1, stream=stream)
+
+    def unfused_primary():
+        # same rays and hits through the separate entry point: instrumented pass and parity sample only (untimed)
         r.trace_primary_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, world, phits, rays, spp=SPP, seed=SEED,
                                     jitter=True, stream=stream)
-
-    def stage_shade1():
-        r.shade_stripes_dev(rays, phits, n_local, thr, rad, brays, key0, row_len, STRIPE, world, seed=SEED + 1, stream=stream)
 
     def stage_bounce_trace():
         r.trace_dev(brays, n_local, bhits, stream=stream)
@@ -120,7 +124,7 @@ def main():
             return rd.gather_rows(fb.view(plan.padded_rows, W).cpu(), plan, gidx.cpu())
         return rd.gather_rows(fb.view(plan.padded_rows, W), plan, gidx)          # [H, W] RGBA8 on every rank
 
-    stages = [stage_primary, stage_shade1, stage_bounce_trace, stage_shade2_resolve, stage_gather]
+    stages = [stage_primary_shade, stage_bounce_trace, stage_shade2_resolve, stage_gather]
 
     def step():
         for st in stages:
@@ -130,9 +134,9 @@ def main():
     # ---- instrumented pass: B, N, T per ray (same kernels with counters on) --------------------------
     r.set_option(rt.OPT_COUNTERS, 1)
     r.counters()
-    stage_primary(); torch.cuda.synchronize()
+    unfused_primary(); torch.cuda.synchronize()
     c_primary = r.counters()
-    stage_shade1(); stage_bounce_trace(); torch.cuda.synchronize()
+    stage_primary_shade(); stage_bounce_trace(); torch.cuda.synchronize()
     c_bounce = r.counters()
     r.set_option(rt.OPT_COUNTERS, 0)
 
@@ -160,9 +164,10 @@ def main():
         elapsed = float(t.item())
 
     ms = [float(np.mean([ev[k][j].elapsed_time(ev[k][j + 1]) for k in range(args.steps)])) for j in range(len(stages))]
-    ms_primary, ms_shade1, ms_btrace, ms_shade2, ms_gather = ms
+    ms_primary, ms_btrace, ms_shade2, ms_gather = ms
 
     frame = step()                                       # one more (untimed) frame for the checksum below
+    unfused_primary()                                    # primary rays / hits in HBM for the parity sample
     torch.cuda.synchronize()
     if rank != 0:
         if world > 1:
@@ -220,9 +225,8 @@ def main():
                            "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
         "frame_sha256": frame_sha,       # RGBA8 framebuffer: identical for every N (decomposition-invariant RNG keys)
         "roofline": roofline, "roofline_hbm": roofline_hbm,
-        "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_ms": round(ms_primary, 4),
+        "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_shade_ms": round(ms_primary, 4),
                     "primary_work_per_ray": w_p, "primary_tflops": round(fl_p * n_real_local / (ms_primary * 1e-3) / 1e12, 3),
-                    "shade1_ms": round(ms_shade1, 4),
                     "bounce_Mrays_s": round(live_b / ms_btrace / 1e3, 1), "bounce_ms": round(ms_btrace, 4),
                     "shade2_resolve_ms": round(ms_shade2, 4), "gather_ms": round(ms_gather, 4)},
     }

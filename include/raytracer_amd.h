@@ -179,6 +179,16 @@ int  rt_shade_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_h
 int  rt_shade_stripes_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
                           uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed,
                           float* d_throughput4, float* d_radiance4, rt_ray* d_rays_out, void* stream);
+
+/* Segment 0 of the path loop in ONE launch: rt_trace_primary_stripes_dev + rt_path_init_dev + rt_shade_stripes_dev
+ * (frag.glsl:89-128, :265-301, :306-354 with throughput = 1, radiance = 0) without the primary rays and hits going
+ * through HBM.  Writes d_throughput4 / d_radiance4 for every local ray slot and, unless NULL, the bounce rays to
+ * d_next_out (dead rays where the path ended); d_rays_out and d_hits_out are optional copies of the primary rays
+ * and hits.  Bit-identical to the three separate calls with `seed` (primary jitter) and `shade_seed`. */
+int  rt_primary_shade_stripes_dev(rt_ctx* ctx, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+                                  uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t seed, int jitter,
+                                  uint32_t shade_seed, rt_ray* d_rays_out, rt_hit* d_hits_out, float* d_throughput4,
+                                  float* d_radiance4, rt_ray* d_next_out, void* stream);
 /* frag.glsl:357-359: per pixel, sum of its spp radiance records / spp, then pow(c, 1/2.6) -> RGBA8 (a = 255).
  * d_linear4 (4 floats per pixel, pre-gamma) and d_rgba8 may each be NULL, not both. */
 int  rt_resolve_dev(rt_ctx* ctx, int slot, const float* d_radiance4, uint64_t n_pixels, uint32_t spp,

@@ -253,6 +253,14 @@ class Renderer:
                                                    stripe_step, seed, _ptr(throughput), _ptr(radiance), _ptr(out_rays),
                                                    _stream_ptr(stream)))
 
+    def primary_shade_stripes_dev(self, w, h, y0, rows, stripe_h, stripe_step, throughput, radiance, next_rays, spp=1,
+                                  seed=0, jitter=False, shade_seed=0, rays=None, hits=None, slot=0, stream=None):
+        """Segment 0 of the path loop in one launch (rt_primary_shade_stripes_dev)."""
+        self._check(self._lib.rt_primary_shade_stripes_dev(self._ctx, slot, w, h, y0, rows, stripe_h, stripe_step, spp, seed,
+                                                           int(bool(jitter)), shade_seed, _ptr(rays), _ptr(hits),
+                                                           _ptr(throughput), _ptr(radiance), _ptr(next_rays),
+                                                           _stream_ptr(stream)))
+
     def resolve_dev(self, radiance, n_pixels, spp, linear=None, rgba8=None, slot=0, stream=None):
         self._check(self._lib.rt_resolve_dev(self._ctx, slot, _ptr(radiance), n_pixels, spp, _ptr(linear), _ptr(rgba8),
                                              _stream_ptr(stream)))

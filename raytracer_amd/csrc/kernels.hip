@@ -463,56 +463,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     }
 }
 
-// Primary rays (frag.glsl:89-128) fused with traceRay.  One wave = one 8x8 pixel tile for one sample.
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
-                                                    uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
-                                                    uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
-                                                    float4* __restrict__ hits, unsigned long long* counters) {
-    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t tile = wave / spp, smp = wave - tile * spp;
-    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const uint32_t x = tx * 8 + (lane & 7), yl = ty * 8 + (lane >> 3);
-    // local row yl -> image row: stripes of stripe_h rows, every stripe_step-th stripe belongs to this launch
-    const uint32_t y = y0 + (yl / stripe_h) * stripe_h * stripe_step + (yl % stripe_h);
-    const bool active = wave < n_waves && x < w && yl < rows && y < h;
-    Counters c = { 0, 0, 0, 0 };
-    if (active) {
-        const uint32_t key = (y * w + x) * spp + smp;                 // RNG key: full-image ray index
-        float uvx = ((float)x + 0.5f) / (float)w;                     // vert.glsl:9-12 pixel centre
-        float uvy = ((float)y + 0.5f) / (float)h;
-        float ndcx = __fmaf_rn(uvx, 2.0f, -1.0f), ndcy = __fmaf_rn(uvy, 2.0f, -1.0f);   // :91
-        if (jitter) {                                                 // :94-103
-            ndcx += (rand01(key, 0u, seed) - 0.5f) * (2.0f / 1920.0f);
-            ndcy += (rand01(key, 1u, seed) - 0.5f) * (2.0f / 1080.0f);
-        }
-        float a = ndcx * cam.half_w, bb = ndcy * cam.half_h;          // :114-115
-        f3 d = mk(__fmaf_rn(bb, cam.ux, a * cam.rx) + cam.fx, __fmaf_rn(bb, cam.uy, a * cam.ry) + cam.fy,
-                  __fmaf_rn(bb, cam.uz, a * cam.rz) + cam.fz);
-        d = norm3(d);                                                 // :113
-        d = norm3(d);                                                 // :120
-        f3 o = mk(cam.px, cam.py, cam.pz);
-        const float tmin = 0.0f, tmax = 1e20f;                        // :266
-        Best b;
-        trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
-        const size_t r = ((size_t)yl * w + x) * spp + smp;
-        if (rays_out) {
-            rays_out[2 * r] = make_float4(o.x, o.y, o.z, tmin);
-            rays_out[2 * r + 1] = make_float4(d.x, d.y, d.z, tmax);
-        }
-        hits[r] = pack_hit(b, tmax);
-    } else if (wave < n_waves && x < w && yl < rows) {
-        // padding row of an interleaved share (image row >= h): a miss record and a dead ray, so that
-        // later stages that sweep the whole local buffer see well-defined input
-        const size_t r = ((size_t)yl * w + x) * spp + smp;
-        if (rays_out) { rays_out[2 * r] = make_float4(0, 0, 0, 0); rays_out[2 * r + 1] = make_float4(0, 0, 0, 0); }
-        hits[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS));
-    }
-    flush_counters<COUNT>(c, active, counters);
-}
-
 // Shading point of a hit: position frag.glsl:275/288, normal :276/:289-293, normalised again as :315.
 __device__ __forceinline__ bool hit_point(const DevScene& s, f3 o, f3 d, float4 hit, f3& p, f3& n) {
     uint32_t prim = __float_as_uint(hit.w);
@@ -534,38 +484,6 @@ __device__ __forceinline__ bool hit_point(const DevScene& s, f3 o, f3 d, float4 
     return true;
 }
 
-// frag.glsl:321-330 for one light, fused: shadow-ray build + closest-hit + lit test.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __restrict__ rays,
-                                                   const float4* __restrict__ hits, uint64_t n, float lx, float ly,
-                                                   float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
-    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4* rp = reinterpret_cast<const float4*>(rays + i);
-    float4 r0 = rp[0], r1 = rp[1];
-    f3 p, nn;
-    if (!hit_point(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), hits[i], p, nn)) {
-        lit[i] = 2;
-        if (srays) { srays[2 * i] = make_float4(0, 0, 0, 0); srays[2 * i + 1] = make_float4(0, 0, 0, 0); }
-        return;
-    }
-    f3 toL = sub3(mk(lx, ly, lz), p);
-    f3 L = norm3(toL);                                       // :321
-    float distance = sqrtf(dot3(toL, toL));                  // :322
-    f3 so = madd3(0.001f, nn, p);                            // :326
-    Best b; Counters c = { 0, 0, 0, 0 };
-    const float tmax = 1e20f;
-    trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
-    bool is_lit = true;
-    if (b.t < tmax) {
-        f3 dl = sub3(madd3(b.t, L, so), p);
-        is_lit = sqrtf(dot3(dl, dl)) > distance;             // :330
-    }
-    lit[i] = is_lit ? 1 : 0;
-    if (srays) { srays[2 * i] = make_float4(so.x, so.y, so.z, 0.0f); srays[2 * i + 1] = make_float4(L.x, L.y, L.z, tmax); }
-}
-
 // sin/cos of 2*pi*x, x in [0,1): exact quarter-turn reduction + fixed fp32 polynomials (same
 // coefficients as the oracle; GLSL leaves sin/cos precision implementation-defined).
 __device__ __forceinline__ void sincos_2pi(float x, float& s, float& c) {
@@ -582,36 +500,6 @@ __device__ __forceinline__ void sincos_2pi(float x, float& s, float& c) {
     else if (q == 2) { ss = -ss; cs = -cs; }
     else if (q == 3) { ss = -ss; }
     s = ss; c = cs;
-}
-
-// frag.glsl:185-203 (cos(theta) = sqrt(1-xi1), sin(theta) = sqrt(xi1) folded analytically) + :340-343.
-__global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __restrict__ rays,
-                                                   const float4* __restrict__ hits, uint64_t n, uint32_t key0,
-                                                   uint32_t seed, float4* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4* rp = reinterpret_cast<const float4*>(rays + i);
-    float4 r0 = rp[0], r1 = rp[1];
-    f3 p, N;
-    if (!hit_point(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), hits[i], p, N)) {
-        out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0);   // tmax 0: traces to a miss
-        return;
-    }
-    const uint32_t key = key0 + (uint32_t)i;
-    float xi1 = rand01(key, 2u, seed), xi2 = rand01(key, 3u, seed);
-    float ct = sqrtf(1.0f - xi1), st = sqrtf(xi1);
-    float sphi, cphi;
-    sincos_2pi(xi2, sphi, cphi);
-    float xs = st * cphi, ys = ct, zs = st * sphi;                                  // :193-195
-    f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);      // :197
-    f3 tX = norm3(cross3(up, N));                                                   // :198
-    f3 tY = cross3(N, tX);                                                          // :199
-    f3 dir = mk(__fmaf_rn(N.x, ys, __fmaf_rn(tY.x, zs, tX.x * xs)), __fmaf_rn(N.y, ys, __fmaf_rn(tY.y, zs, tX.y * xs)),
-                __fmaf_rn(N.z, ys, __fmaf_rn(tY.z, zs, tX.z * xs)));                // :201
-    dir = norm3(dir);                                                               // :202
-    f3 o = madd3(0.001f, N, p);                                                     // :342
-    out[2 * i] = make_float4(o.x, o.y, o.z, 0.0f);
-    out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
 }
 
 // ---- shading (frag.glsl:205-263) + one bounce of the path loop (:310-354) ------------------------------
@@ -664,30 +552,19 @@ __device__ __forceinline__ f3 hemisphere(f3 N, float xi1, float xi2) {          
     return norm3(dir);
 }
 
+// One segment of the path loop (frag.glsl:310-354) for one path: T, C in/out; returns false when the path ends
+// here (miss or dead ray: T and C are left as they are).  With want_next the bounce ray (o, dir) is produced
+// and T updated (:340-350); key = index of the path in the FULL frame (decomposition-invariant RNG).
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
-                                                  const float4* __restrict__ hits, uint64_t n, uint32_t key0,
-                                                  uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step,
-                                                  uint32_t seed, float4* __restrict__ thr, float4* __restrict__ rad,
-                                                  float4* __restrict__ out) {
-    extern __shared__ int stack[];
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4* rp = reinterpret_cast<const float4*>(rays + i);
-    float4 r0 = rp[0], r1 = rp[1];
-    float4 hit = hits[i];
+__device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r1, float4 hit, f3& T, f3& C, uint32_t key,
+                                          uint32_t seed, bool want_next, int* stk, f3& o, f3& dir) {
     f3 P, N;
     f3 d = mk(r1.x, r1.y, r1.z);
-    if (!(r1.w > r0.w) || !hit_point(s, mk(r0.x, r0.y, r0.z), d, hit, P, N)) {     // :351-353 the path ends
-        if (out) { out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0); }
-        return;
-    }
+    if (!(r1.w > r0.w) || !hit_point(s, mk(r0.x, r0.y, r0.z), d, hit, P, N)) return false;   // :351-353 the path ends
     const uint32_t prim = __float_as_uint(hit.w);
     const uint32_t mid = (prim & RT_SPHERE_BIT) ? s.sphere_mat[prim & ~RT_SPHERE_BIT]
                                                 : __float_as_uint(s.normals[(size_t)prim * 3].w);
     const Mat m = load_mat(s, mid);
-    float4 t4 = thr[i], c4 = rad[i];
-    f3 T = mk(t4.x, t4.y, t4.z), C = mk(c4.x, c4.y, c4.z);
     C = mk(__fmaf_rn(T.x * m.emission.x, m.strength, C.x), __fmaf_rn(T.y * m.emission.y, m.strength, C.y),
            __fmaf_rn(T.z * m.emission.z, m.strength, C.z));                         // :313
     f3 V = norm3(mk(-d.x, -d.y, -d.z));                                             // :316
@@ -700,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __re
         f3 so = madd3(0.001f, N, P);
         Best b; Counters c = { 0, 0, 0, 0 };
         const float tmax = 1e20f;
-        trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
+        trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stk);
         bool lit = true;
         if (b.t < tmax) {
             f3 dl = sub3(madd3(b.t, L, so), P);
@@ -714,24 +591,175 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __re
                    __fmaf_rn((T.z * B.z) * (l1.z * ia), NdotL, C.z));                // :335-336
         }
     }
-    if (out == nullptr) {                  // last segment of a path: only its radiance is still needed
-        rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
+    if (!want_next) return true;           // last segment of a path: only its radiance is still needed
+    dir = hemisphere(N, rand01(key, 2u, seed), rand01(key, 3u, seed));              // :340
+    o = madd3(0.001f, N, P);                                                        // :342
+    float NdotR = max0(dot3(N, dir));                                               // :345
+    float pdf = NdotR / kPi;                                                        // :346
+    f3 B = brdf(m, N, V, dir);                                                      // :348
+    T = mk(T.x * ((B.x * NdotR) / pdf), T.y * ((B.y * NdotR) / pdf), T.z * ((B.z * NdotR) / pdf));   // :350
+    return true;
+}
+
+// Primary rays (frag.glsl:89-128) fused with traceRay.  One wave = one 8x8 pixel tile for one sample.
+// With SHADE the first segment of the path loop (:310-354, throughput 1, radiance 0) runs in the same kernel:
+// the primary ray and its hit never travel through HBM (rays_out / hits become optional outputs), and the
+// path-state buffers are written once instead of filled, read and written.
+struct ShadeOut { float4* thr; float4* rad; float4* next; uint32_t seed; };
+template <int MODE, bool COUNT, bool SHADE>
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
+                                                    uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
+                                                    uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
+                                                    float4* __restrict__ hits, unsigned long long* counters, ShadeOut so) {
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t tile = wave / spp, smp = wave - tile * spp;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t x = tx * 8 + (lane & 7), yl = ty * 8 + (lane >> 3);
+    // local row yl -> image row: stripes of stripe_h rows, every stripe_step-th stripe belongs to this launch
+    const uint32_t y = y0 + (yl / stripe_h) * stripe_h * stripe_step + (yl % stripe_h);
+    const bool active = wave < n_waves && x < w && yl < rows && y < h;
+    Counters c = { 0, 0, 0, 0 };
+    if (active) {
+        const uint32_t key = (y * w + x) * spp + smp;                 // RNG key: full-image ray index
+        float uvx = ((float)x + 0.5f) / (float)w;                     // vert.glsl:9-12 pixel centre
+        float uvy = ((float)y + 0.5f) / (float)h;
+        float ndcx = __fmaf_rn(uvx, 2.0f, -1.0f), ndcy = __fmaf_rn(uvy, 2.0f, -1.0f);   // :91
+        if (jitter) {                                                 // :94-103
+            ndcx += (rand01(key, 0u, seed) - 0.5f) * (2.0f / 1920.0f);
+            ndcy += (rand01(key, 1u, seed) - 0.5f) * (2.0f / 1080.0f);
+        }
+        float a = ndcx * cam.half_w, bb = ndcy * cam.half_h;          // :114-115
+        f3 d = mk(__fmaf_rn(bb, cam.ux, a * cam.rx) + cam.fx, __fmaf_rn(bb, cam.uy, a * cam.ry) + cam.fy,
+                  __fmaf_rn(bb, cam.uz, a * cam.rz) + cam.fz);
+        d = norm3(d);                                                 // :113
+        d = norm3(d);                                                 // :120
+        f3 o = mk(cam.px, cam.py, cam.pz);
+        const float tmin = 0.0f, tmax = 1e20f;                        // :266
+        Best b;
+        int* stk = stack + (MODE != kBrute ? threadIdx.x : 0);
+        trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stk);
+        const size_t r = ((size_t)yl * w + x) * spp + smp;
+        const float4 r0 = make_float4(o.x, o.y, o.z, tmin), r1 = make_float4(d.x, d.y, d.z, tmax), hit = pack_hit(b, tmax);
+        if (rays_out) { rays_out[2 * r] = r0; rays_out[2 * r + 1] = r1; }
+        if (hits) hits[r] = hit;
+        if (SHADE) {
+            f3 T = mk(1.0f, 1.0f, 1.0f), C = mk(0.0f, 0.0f, 0.0f), no, nd;             // :306-307
+            const bool go = shade_one<MODE>(s, r0, r1, hit, T, C, key, so.seed, so.next != nullptr, stk, no, nd);
+            so.thr[r] = make_float4(T.x, T.y, T.z, 0.0f);
+            so.rad[r] = make_float4(C.x, C.y, C.z, 0.0f);
+            if (so.next) {
+                so.next[2 * r] = go ? make_float4(no.x, no.y, no.z, 0.0f) : make_float4(0, 0, 0, 0);
+                so.next[2 * r + 1] = go ? make_float4(nd.x, nd.y, nd.z, 1e20f) : make_float4(0, 0, 0, 0);
+            }
+        }
+    } else if (wave < n_waves && x < w && yl < rows) {
+        // padding row of an interleaved share (image row >= h): a miss record and a dead ray, so that
+        // later stages that sweep the whole local buffer see well-defined input
+        const size_t r = ((size_t)yl * w + x) * spp + smp;
+        if (rays_out) { rays_out[2 * r] = make_float4(0, 0, 0, 0); rays_out[2 * r + 1] = make_float4(0, 0, 0, 0); }
+        if (hits) hits[r] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_MISS));
+        if (SHADE) {
+            so.thr[r] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            so.rad[r] = make_float4(0, 0, 0, 0);
+            if (so.next) { so.next[2 * r] = make_float4(0, 0, 0, 0); so.next[2 * r + 1] = make_float4(0, 0, 0, 0); }
+        }
+    }
+    flush_counters<COUNT>(c, active, counters);
+}
+
+// frag.glsl:321-330 for one light, fused: shadow-ray build + closest-hit + lit test.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __restrict__ rays,
+                                                   const float4* __restrict__ hits, uint64_t n, float lx, float ly,
+                                                   float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* rp = reinterpret_cast<const float4*>(rays + i);
+    float4 r0 = rp[0], r1 = rp[1];
+    f3 p, nn;
+    if (!hit_point(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), hits[i], p, nn)) {
+        lit[i] = 2;
+        if (srays) { srays[2 * i] = make_float4(0, 0, 0, 0); srays[2 * i + 1] = make_float4(0, 0, 0, 0); }
         return;
     }
+    f3 toL = sub3(mk(lx, ly, lz), p);
+    f3 L = norm3(toL);                                       // :321
+    float distance = sqrtf(dot3(toL, toL));                  // :322
+    f3 so = madd3(0.001f, nn, p);                            // :326
+    Best b; Counters c = { 0, 0, 0, 0 };
+    const float tmax = 1e20f;
+    trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
+    bool is_lit = true;
+    if (b.t < tmax) {
+        f3 dl = sub3(madd3(b.t, L, so), p);
+        is_lit = sqrtf(dot3(dl, dl)) > distance;             // :330
+    }
+    lit[i] = is_lit ? 1 : 0;
+    if (srays) { srays[2 * i] = make_float4(so.x, so.y, so.z, 0.0f); srays[2 * i + 1] = make_float4(L.x, L.y, L.z, tmax); }
+}
+
+// frag.glsl:185-203 (cos(theta) = sqrt(1-xi1), sin(theta) = sqrt(xi1) folded analytically) + :340-343.
+__global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __restrict__ rays,
+                                                   const float4* __restrict__ hits, uint64_t n, uint32_t key0,
+                                                   uint32_t seed, float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* rp = reinterpret_cast<const float4*>(rays + i);
+    float4 r0 = rp[0], r1 = rp[1];
+    f3 p, N;
+    if (!hit_point(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), hits[i], p, N)) {
+        out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0);   // tmax 0: traces to a miss
+        return;
+    }
+    const uint32_t key = key0 + (uint32_t)i;
+    float xi1 = rand01(key, 2u, seed), xi2 = rand01(key, 3u, seed);
+    float ct = sqrtf(1.0f - xi1), st = sqrtf(xi1);
+    float sphi, cphi;
+    sincos_2pi(xi2, sphi, cphi);
+    float xs = st * cphi, ys = ct, zs = st * sphi;                                  // :193-195
+    f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);      // :197
+    f3 tX = norm3(cross3(up, N));                                                   // :198
+    f3 tY = cross3(N, tX);                                                          // :199
+    f3 dir = mk(__fmaf_rn(N.x, ys, __fmaf_rn(tY.x, zs, tX.x * xs)), __fmaf_rn(N.y, ys, __fmaf_rn(tY.y, zs, tX.y * xs)),
+                __fmaf_rn(N.z, ys, __fmaf_rn(tY.z, zs, tX.z * xs)));                // :201
+    dir = norm3(dir);                                                               // :202
+    f3 o = madd3(0.001f, N, p);                                                     // :342
+    out[2 * i] = make_float4(o.x, o.y, o.z, 0.0f);
+    out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
+                                                  const float4* __restrict__ hits, uint64_t n, uint32_t key0,
+                                                  uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step,
+                                                  uint32_t seed, float4* __restrict__ thr, float4* __restrict__ rad,
+                                                  float4* __restrict__ out) {
+    extern __shared__ int stack[];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* rp = reinterpret_cast<const float4*>(rays + i);
+    float4 r0 = rp[0], r1 = rp[1];
+    float4 hit = hits[i];
     // RNG key = index of this path in the FULL frame, so that a striped share draws the same numbers
     uint32_t key = key0 + (uint32_t)i;
     if (row_len) {
         const uint32_t yl = (uint32_t)(i / row_len), rem = (uint32_t)(i - (uint64_t)yl * row_len);
         key = key0 + ((yl / stripe_h) * stripe_h * stripe_step + yl % stripe_h) * row_len + rem;
     }
-    f3 dir = hemisphere(N, rand01(key, 2u, seed), rand01(key, 3u, seed));           // :340
-    f3 o = madd3(0.001f, N, P);                                                     // :342
-    float NdotR = max0(dot3(N, dir));                                               // :345
-    float pdf = NdotR / kPi;                                                        // :346
-    f3 B = brdf(m, N, V, dir);                                                      // :348
-    T = mk(T.x * ((B.x * NdotR) / pdf), T.y * ((B.y * NdotR) / pdf), T.z * ((B.z * NdotR) / pdf));   // :350
-    thr[i] = make_float4(T.x, T.y, T.z, 0.0f);
+    float4 t4 = make_float4(0, 0, 0, 0), c4 = make_float4(0, 0, 0, 0);
+    const bool alive = r1.w > r0.w && __float_as_uint(hit.w) != RT_MISS;
+    if (alive) { t4 = thr[i]; c4 = rad[i]; }
+    f3 T = mk(t4.x, t4.y, t4.z), C = mk(c4.x, c4.y, c4.z), o, dir;
+    if (!shade_one<MODE>(s, r0, r1, hit, T, C, key, seed, out != nullptr, stack + (MODE != kBrute ? threadIdx.x : 0), o, dir)) {
+        if (out) { out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0); }
+        return;
+    }
     rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
+    if (out == nullptr) return;
+    thr[i] = make_float4(T.x, T.y, T.z, 0.0f);
     out[2 * i] = make_float4(o.x, o.y, o.z, 0.0f);
     out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
 }
@@ -920,9 +948,11 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
 hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, bool count, uint32_t w, uint32_t h,
                           uint32_t y0, uint32_t rows, uint32_t stripe_h, uint32_t stripe_step, uint32_t spp,
                           uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits,
-                          unsigned long long* d_counters, hipStream_t st) {
+                          unsigned long long* d_counters, hipStream_t st, const PrimaryShade* shade) {
     if (rows == 0 || w == 0 || spp == 0) return hipSuccess;
     if (stripe_h == 0 || stripe_step == 0) return hipErrorInvalidValue;
+    if (!shade && !d_hits) return hipErrorInvalidValue;
+    if (shade && (!shade->d_throughput || !shade->d_radiance)) return hipErrorInvalidValue;
     const uint32_t tiles_x = (w + 7) / 8, tiles_y = (rows + 7) / 8;
     const uint64_t n_waves64 = (uint64_t)tiles_x * tiles_y * spp;
     if (n_waves64 > 0xFFFFFFFFull) return hipErrorInvalidValue;
@@ -930,9 +960,11 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
     dim3 g((n_waves + kBlock / 64 - 1) / (kBlock / 64)), b(kBlock);
     float4* rays = reinterpret_cast<float4*>(d_rays_out);
     float4* hits = reinterpret_cast<float4*>(d_hits);
-#define RT_LAUNCH(M, C) hipLaunchKernelGGL((k_primary<M, C>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
-                                           jitter, tiles_x, n_waves, rays, hits, d_counters)
-#define RT_LAUNCH_M(M) do { if (count) RT_LAUNCH(M, true); else RT_LAUNCH(M, false); } while (0)
+    ShadeOut so = { nullptr, nullptr, nullptr, 0u };
+    if (shade) so = ShadeOut{ shade->d_throughput, shade->d_radiance, reinterpret_cast<float4*>(shade->d_next), shade->seed };
+#define RT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_primary<M, C, S>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
+                                              jitter, tiles_x, n_waves, rays, hits, d_counters, so)
+#define RT_LAUNCH_M(M) do { if (shade) RT_LAUNCH(M, false, true); else if (count) RT_LAUNCH(M, true, false); else RT_LAUNCH(M, false, false); } while (0)
     if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_M

@@ -50,10 +50,14 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
                         const uint32_t* d_perm = nullptr /* order in which rays are handed out (strip kernel only) */,
                         const uint32_t* d_perm_on = nullptr /* device flag: 0 = ignore d_perm */);
 
+// With `shade` the first segment of the path loop runs in the same kernel (throughput 1, radiance 0 going in):
+// d_throughput / d_radiance are written for every local ray slot, d_next (may be null) receives the bounce rays,
+// and d_rays_out / d_hits become optional.  Counters are not collected in that variant.
+struct PrimaryShade { float4* d_throughput; float4* d_radiance; rt_ray* d_next; uint32_t seed; };
 hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, bool count, uint32_t w, uint32_t h,
                           uint32_t y0, uint32_t rows, uint32_t stripe_h, uint32_t stripe_step, uint32_t spp,
                           uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits,
-                          unsigned long long* d_counters, hipStream_t st);
+                          unsigned long long* d_counters, hipStream_t st, const PrimaryShade* shade = nullptr);
 
 hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
                          float lx, float ly, float lz, rt_ray* d_shadow_rays, uint8_t* d_lit, hipStream_t st);

@@ -512,6 +512,24 @@ int rt_trace_primary_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, ui
     return RT_OK;
 }
 
+int rt_primary_shade_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+                                 uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t seed, int jitter,
+                                 uint32_t shade_seed, rt_ray* d_rays_out, rt_hit* d_hits_out, float* d_throughput4,
+                                 float* d_radiance4, rt_ray* d_next_out, void* stream) {
+    int rc = check_stage(c, slot, true);
+    if (rc) return rc;
+    if (!d_throughput4 || !d_radiance4 || w == 0 || h == 0 || spp == 0 || stripe_h == 0 || stripe_step == 0)
+        return fail(c, RT_E_INVALID, "primary+shade: bad arguments");
+    if ((uint64_t)w * h * spp > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "primary: w*h*spp exceeds 2^32-1 (RNG key width)");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
+    const PrimaryShade ps = { reinterpret_cast<float4*>(d_throughput4), reinterpret_cast<float4*>(d_radiance4), d_next_out, shade_seed };
+    RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), false, w, h, y0, rows, stripe_h, stripe_step,
+                             spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st, &ps));
+    return RT_OK;
+}
+
 int rt_trace_primary_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows, uint32_t spp,
                          uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) {
     if (c && (uint64_t)y0 + rows > h) return fail(c, RT_E_INVALID, "primary: y0 + rows > h");
@@ -639,14 +657,13 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         float4* rad = reinterpret_cast<float4*>(base + n * 96);
         uint32_t* rgba = reinterpret_cast<uint32_t*>(base + n * 112);
         const DevScene ds = c->dev_scene(r);
-        RT_HIP_SLOT(r, launch_fill(thr, n, 1.f, 1.f, 1.f, 0.f, r.stream));
-        RT_HIP_SLOT(r, launch_fill(rad, n, 0.f, 0.f, 0.f, 0.f, r.stream));
-        RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, ra, hits, r.d_counters, r.stream));
+        // segment 0: primary rays + their shading in one kernel (the primary rays and hits stay in registers)
+        const PrimaryShade ps = { thr, rad, bounces > 1 ? ra : nullptr, seed + 1u };
+        RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, nullptr, nullptr, r.d_counters, r.stream, &ps));
         const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
-        for (uint32_t b = 0; b < bounces; ++b) {
+        for (uint32_t b = 1; b < bounces; ++b) {
+            RT_HIP_SLOT(r, trace_rays(c, r, false, false, ra, n, hits, nullptr, r.stream));
             RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, 0, 1, 1, seed + 1u + b, thr, rad, b + 1 < bounces ? rb : nullptr, r.stream));
-            if (b + 1 < bounces)
-                RT_HIP_SLOT(r, trace_rays(c, r, false, false, rb, n, hits, nullptr, r.stream));
             std::swap(ra, rb);
         }
         RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));

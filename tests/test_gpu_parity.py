@@ -487,6 +487,39 @@ def test_path_loop_stages_bit_exact(renderer, torch_dev, mode, with_lights):
     assert o_rad[:, :3].sum() > 0 and (not with_lights or o_rad[:, :3].mean() > 0.05)
 
 
+@pytest.mark.parametrize("with_lights", [False, True])
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q])
+def test_fused_primary_shade_equals_the_three_separate_stages(renderer, torch_dev, mode, with_lights):
+    """rt_primary_shade_stripes_dev = rt_path_init_dev + rt_trace_primary_stripes_dev + rt_shade_stripes_dev, bit for bit:
+    whole frame, and a striped share with a padding stripe (dead slots must read throughput 1, radiance 0, dead ray)."""
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    renderer.create_data(tris, sph, _lights2() if with_lights else None)
+    renderer.update_camera(rt.default_camera(52 / 40))
+    w, h, spp, seed = 52, 40, 3, 5
+    s = torch.cuda.current_stream()
+    for world, rank, sh in ((1, 0, 8), (3, 2, 8), (2, 1, 16)):
+        p = rd.stripe_plan(h, world, rank, sh)
+        n = p.padded_rows * w * spp
+        f = lambda k: torch.full((n * k,), 7.0, dtype=torch.float32, device="cuda")
+        ra, hits, thr, rad, nxt = f(8), f(4), f(4), f(4), f(8)
+        renderer.path_init_dev(n, thr, rad, stream=s)
+        renderer.trace_primary_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, hits, ra, spp=spp, seed=seed, jitter=True, stream=s)
+        renderer.shade_stripes_dev(ra, hits, n, thr, rad, nxt, p.y0 * w * spp, w * spp, sh, world, seed=seed + 1, stream=s)
+        ra2, hits2, thr2, rad2, nxt2 = f(8), f(4), f(4), f(4), f(8)
+        renderer.primary_shade_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, thr2, rad2, nxt2, spp=spp, seed=seed,
+                                           jitter=True, shade_seed=seed + 1, rays=ra2, hits=hits2, stream=s)
+        thr3, rad3 = f(4), f(4)                       # last-segment form: no next rays, no copies of rays / hits
+        renderer.primary_shade_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, thr3, rad3, None, spp=spp, seed=seed,
+                                           jitter=True, shade_seed=seed + 1, stream=s)
+        torch.cuda.synchronize()
+        for a, b, what in ((ra, ra2, "rays"), (hits, hits2, "hits"), (thr, thr2, "throughput"), (rad, rad2, "radiance"),
+                           (nxt, nxt2, "next rays"), (rad, rad3, "radiance, last-segment form")):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (world, rank, sh, what)
+        assert (not with_lights) or float(rad.view(-1, 4)[:, :3].sum()) > 0
+
+
 def test_rt_render_matches_oracle_frame():
     """rt_render (host RGBA8, two replicas on the one GPU = the in-process multi-device path) against orc_render;
     the reference's own SAMPLES/BOUNCES are 10/8 (frag.glsl:3-4), here 4/5 on 96x72 to keep the oracle quick."""
