@@ -41,6 +41,9 @@ bool next_corner(const char*& p, Corner& c) {
     return true;
 }
 
+// a keyword ends at white space or at the end of the line / file (a bare `f` is a malformed record, not a comment)
+bool is_end(char c) { return c == ' ' || c == '\t' || c == '\0' || c == '\n' || c == '\r'; }
+
 bool resolve(long idx, size_t count, size_t& out) {
     if (idx > 0 && (size_t)idx <= count) { out = (size_t)idx - 1; return true; }
     if (idx < 0 && (size_t)(-idx) <= count) { out = count - (size_t)(-idx); return true; }
@@ -70,15 +73,15 @@ extern "C" int rt_load_obj(const char* path, const void* material48, void* tris1
         while (!line.empty() && line.back() != '\n' && std::fgets(buf, sizeof buf, f)) line.append(buf);   // long lines
         const char* p = line.c_str();
         while (*p == ' ' || *p == '\t') ++p;
-        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+        if (p[0] == 'v' && is_end(p[1])) {
             Vec3 v{ 0, 0, 0 };
             if (std::sscanf(p + 1, "%f %f %f", &v.x, &v.y, &v.z) != 3) { rc = RT_E_INVALID; break; }
             pos.push_back(v);
-        } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
+        } else if (p[0] == 'v' && p[1] == 'n' && is_end(p[2])) {
             Vec3 v{ 0, 0, 0 };
             if (std::sscanf(p + 2, "%f %f %f", &v.x, &v.y, &v.z) != 3) { rc = RT_E_INVALID; break; }
             nrm.push_back(v);
-        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+        } else if (p[0] == 'f' && is_end(p[1])) {
             face.clear();
             const char* q = p + 1;
             Corner c;

@@ -1,0 +1,98 @@
+// Host-code sanitizer driver (ASan + UBSan, CPU only): exercises the BVH builder / flatteners, the scene generators and
+// the OBJ reader on ordinary and degenerate inputs.  Built and run by tests/test_host_sanitizers.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "../../raytracer_amd/csrc/bvh.hpp"
+#include "../../raytracer_amd/host/rt_types.hpp"
+
+using namespace rt;
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
+
+static void build_and_flatten(const std::vector<Triangle>& tris, int max_leaf, int threads) {
+    std::vector<Aabb> boxes(tris.size());
+    for (size_t i = 0; i < tris.size(); ++i) {
+        boxes[i].reset();
+        boxes[i].grow(&tris[i].m_v0.m_position.x); boxes[i].grow(&tris[i].m_v1.m_position.x); boxes[i].grow(&tris[i].m_v2.m_position.x);
+    }
+    BuildParams bp; bp.max_leaf = max_leaf; bp.max_depth = 30; bp.threads = threads;
+    BuildResult br;
+    build_bvh2(boxes.data(), (uint32_t)boxes.size(), bp, br);
+    FlatBvh2 f2; flatten_bvh2(br, 1e-5f, f2);
+    FlatBvh4q f4; flatten_bvh4q(br, 1e-5f, f4);
+    EXPECT(f2.tri_order.size() == tris.size());
+    EXPECT(f4.tri_order.size() == tris.size());
+    EXPECT(f2.nodes.size() == (size_t)f2.n_nodes * 16);
+    EXPECT(f4.nodes.size() == (size_t)f4.n_nodes * 16);
+    std::vector<char> seen(tris.size(), 0);
+    for (uint32_t id : f4.tri_order) { EXPECT(id < tris.size()); if (id < tris.size()) { EXPECT(!seen[id]); seen[id] = 1; } }
+    EXPECT(bvh2_stack_need(br) <= 32);
+}
+
+int main(int argc, char** argv) {
+    // soups of several sizes, thread counts and leaf sizes
+    for (uint32_t n : { 0u, 1u, 2u, 5u, 33u, 1000u, 50000u }) {
+        std::vector<Triangle> t(n);
+        EXPECT(rt_gen_soup(0x5EED0001ull, n, 0.02f, t.data(), n) == n);
+        for (int leaf : { 1, 4, 8 }) for (int th : { 1, 5 }) build_and_flatten(t, leaf, th);
+    }
+    // degenerate: all triangles identical (forces median splits down to the depth budget), zero-area, huge coordinates
+    {
+        std::vector<Triangle> t(5000);
+        std::memset(t.data(), 0, t.size() * sizeof(Triangle));
+        for (auto& x : t) { x.m_v1.m_position.x = 1.f; x.m_v2.m_position.y = 1.f; }
+        build_and_flatten(t, 4, 3);
+        for (auto& x : t) { x.m_v1.m_position.x = 0.f; x.m_v2.m_position.y = 0.f; }
+        build_and_flatten(t, 4, 3);
+        for (size_t i = 0; i < t.size(); ++i) { t[i].m_v0.m_position.x = 1e30f * (float)(i % 7); t[i].m_v1.m_position.y = -1e30f; t[i].m_v2.m_position.z = 3e37f; }
+        build_and_flatten(t, 2, 2);
+    }
+    // generators
+    {
+        std::vector<Triangle> c(rt_gen_cornell_triangles(nullptr, 0));
+        EXPECT(c.size() == 12 && rt_gen_cornell_triangles(c.data(), 12) == 12);
+        std::vector<Sphere> s(rt_gen_cornell_spheres(nullptr, 0));
+        EXPECT(s.size() == 3 && rt_gen_cornell_spheres(s.data(), 2) == 3);     // cap < count: writes 2, reports 3
+        const float ctr[3] = { 0, 0, 0 }, mat[12] = { 0 };
+        const uint32_t n = rt_gen_sphere_geometry(ctr, 1.f, 7, 9, mat, nullptr, 0);
+        std::vector<Triangle> g(n);
+        EXPECT(rt_gen_sphere_geometry(ctr, 1.f, 7, 9, mat, g.data(), n) == n);
+        build_and_flatten(g, 4, 2);
+        std::vector<rt_ray> rays(1000);
+        rt_gen_random_rays(0x5EED0002ull, 12345, rays.size(), rays.data());
+        for (const rt_ray& r : rays) EXPECT(std::fabs(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz - 1.f) < 1e-5f);
+        CameraUBO cam; const float p[3] = { 0, 4, 1 }, l[3] = { 0, 0, 1 };
+        rt_camera_look_at(p, l, 45.f, 1.2f, &cam);
+    }
+    // OBJ reader: well-formed, malformed, truncated and long-line inputs (paths from argv[1] = scratch dir)
+    if (argc > 1) {
+        const std::string dir = argv[1];
+        auto write = [&](const char* name, const std::string& text) { std::string p = dir + "/" + name; FILE* f = std::fopen(p.c_str(), "wb"); std::fwrite(text.data(), 1, text.size(), f); std::fclose(f); return p; };
+        uint64_t n = 0;
+        std::string ok = "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nf 1 2 3 4\nf -1//1 -2//1 -3//1\n";
+        std::string p = write("ok.obj", ok);
+        EXPECT(rt_load_obj(p.c_str(), nullptr, nullptr, 0, &n) == RT_OK && n == 3);
+        std::vector<Triangle> t(2);                                            // cap < count
+        EXPECT(rt_load_obj(p.c_str(), nullptr, t.data(), 2, &n) == RT_OK && n == 3);
+        std::string big = "v 0 0 0\nv 1 0 0\nv 0 1 0\nf";
+        for (int k = 0; k < 5000; ++k) big += (k % 3 == 0) ? " 1" : (k % 3 == 1 ? " 2" : " 3");     // one 10 kB line
+        big += "\n";
+        p = write("big.obj", big);
+        EXPECT(rt_load_obj(p.c_str(), nullptr, nullptr, 0, &n) == RT_OK && n == 4998);
+        for (const char* bad : { "f 1 2 3\n", "v 1 2\n", "v 0 0 0\nf 1/ 1/ 1/\nf 1 1\n", "v 0 0 0\nf 0 0 0\n", "v 0 0 0\nf 1//9 1//9 1//9\n", "f", "v", "vn 1\n" }) {
+            p = write("bad.obj", bad);
+            EXPECT(rt_load_obj(p.c_str(), nullptr, nullptr, 0, &n) == RT_E_INVALID);
+        }
+        EXPECT(rt_load_obj((dir + "/missing.obj").c_str(), nullptr, nullptr, 0, &n) == RT_E_INVALID);
+        EXPECT(rt_load_obj(nullptr, nullptr, nullptr, 0, &n) == RT_E_INVALID);
+    }
+    std::printf("host sanitizer driver: %d failures\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,27 @@
+"""Host code of the library (BVH builder and flatteners, scene generators, OBJ reader) under ASan + UBSan on the CPU.
+GPU sanitizers are not available on the pool; the kernels are covered by the parity tests instead."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_sources_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "host_san"
+    srcs = [os.path.join(ROOT, "tests", "host_san", "driver.cpp")] + [os.path.join(CSRC, f) for f in ("bvh.cpp", "scene_gen.cpp", "obj_loader.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", *srcs, "-o", str(exe), "-lpthread"]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)                      # ASan must be the first library in the process
+    scratch = tmp_path / "obj"
+    scratch.mkdir()
+    r = subprocess.run([str(exe), str(scratch)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "0 failures" in r.stdout
