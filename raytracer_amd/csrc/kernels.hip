@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
-                                                        unsigned long long* __restrict__ work /* chunk cursor, 0 at launch */,
+                                                        unsigned long long* __restrict__ work /* 8 chunk cursors, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
                                                         const uint32_t* __restrict__ perm_on /* device flag, null = on */,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
@@ -361,7 +361,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     const float4* __restrict__ tris = s.tris;
     if (perm && perm_on && *perm_on == 0u) perm = nullptr;             // launch_bin found the buffer coherent already
     uint64_t cursor = 0, end = 0;                                     // wave-uniform: the chunk being handed out
-    bool more = true;                                                 // wave-uniform: the global cursor is not exhausted
+    bool more = true;                                                 // wave-uniform: some cursor is not exhausted
+    const uint64_t n_chunks = (n + strip - 1) / strip;
+    const uint32_t per_q = (uint32_t)((n_chunks + 7) / 8);            // chunks per eighth
+    uint32_t q = blockIdx.x & 7u, q_tried = 0;                        // workgroups go round-robin over the 8 XCDs
     stk[0] = kDone;
     int node = kDone, sp = 1;
     uint64_t my = 0;
@@ -378,13 +381,21 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
         if (cursor >= end && more && n_idle >= refill) {
-            unsigned long long c0 = 0;
-            if ((threadIdx.x & 63) == 0) c0 = atomicAdd(work, (unsigned long long)strip);
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(c0 >> 32));
-            cursor = ((uint64_t)hi << 32) | lo;
-            more = cursor < n;
-            end = more ? ((cursor + strip < n) ? cursor + strip : n) : 0;
-            if (!more) cursor = 0;
+            // draw the next chunk: own eighth of the buffer first (one cursor per XCD, so that an XCD's L2 sees one
+            // contiguous -- with binning: spatially compact -- part of the rays), then the other eighths
+            cursor = end = 0;
+            while (more) {
+                unsigned long long c0 = 0;
+                if ((threadIdx.x & 63) == 0) c0 = atomicAdd(&work[q], 1ull);
+                const uint64_t ci = (uint64_t)q * per_q + __builtin_amdgcn_readfirstlane((uint32_t)c0);
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c0) < per_q && ci < n_chunks) {
+                    cursor = ci * strip;
+                    end = (cursor + strip < n) ? cursor + strip : n;
+                    break;
+                }
+                q = (q + 1u) & 7u;
+                if (++q_tried == 8u) more = false;
+            }
         }
         if (cursor < end && n_idle >= refill) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
@@ -922,8 +933,8 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         // strip kernel: persistent waves, as many blocks as the chip holds at once (LDS-limited), never more than
         // there are chunks.  The chunk cursor is one slot of a ring behind the counters, zeroed on the stream.
         static std::atomic<uint32_t> seq{0};
-        unsigned long long* work = d_counters + kNumCounters + (seq.fetch_add(1) % kWorkSlots);
-        hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned long long), st);
+        unsigned long long* work = d_counters + kNumCounters + (size_t)(seq.fetch_add(1) % kWorkSlots) * 8;
+        hipError_t e = hipMemsetAsync(work, 0, 8 * sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;
         const size_t lds = stack_bytes(s, mode);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));

@@ -75,7 +75,7 @@ hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t 
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
 
 constexpr int kStackDepth = 32;   // per-lane traversal stack entries held in LDS
-constexpr int kWorkSlots = 64;    // ring of chunk cursors of the strip kernel, stored behind the counters (one per launch in flight)
+constexpr int kWorkSlots = 64;    // ring of chunk-cursor sets (8 cursors each) of the strip kernel, stored behind the counters (one set per launch in flight)
 constexpr int kNumCounters = 8;   // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves
 
 }  // namespace rt
