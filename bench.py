@@ -40,6 +40,7 @@ W, H, SPP, SEED, STRIPE = 3840, 2160, 4, 1, 8
 PEAK_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 CPU_SAMPLE = 65536            # rays per generation in the CPU-baseline / parity sample
+CPU_BVH_SAMPLE = 1 << 24      # rays per generation for the CPU BVH walk (fair CPU row + wide parity gate)
 
 
 def flops_bytes_per_ray(c, generated):
@@ -256,6 +257,25 @@ def main():
                                "sample": f"{CPU_SAMPLE} primary + {CPU_SAMPLE} bounce rays of the same frame (seeded "
                                          f"subset), brute force over all 259212 triangles, {cpu_s:.1f} s"}
         out["parity"] = {"sample_rays": 2 * CPU_SAMPLE, "prim_id_mismatches": mism, "hit_records_bit_exact": bool(exact)}
+        # SURVEY 8(d) second CPU row, "build CPU BVH, not reference": the oracle walks the BVH2 that the library's host
+        # builder flattens (handed over as data).  Fair CPU figure, and a wider parity gate (its walk is tested equal
+        # to the brute-force loop in tests/test_bvh_host.py).
+        _, nodes2, order2 = rt.bvh_build_host(tris, layout=rt.TRAVERSAL_BVH2)
+        m = min(CPU_BVH_SAMPLE, live)
+        w_rays = rays.view(-1, 8)[:m].cpu().numpy().view(rt.RAY).ravel()
+        w_brays = brays.view(-1, 8)[:m].cpu().numpy().view(rt.RAY).ravel()
+        tc = time.perf_counter()
+        w_hits = oracle.trace_bvh2(sc, nodes2, order2, w_rays)
+        w_bhits = oracle.trace_bvh2(sc, nodes2, order2, w_brays)
+        walk_s = time.perf_counter() - tc
+        g_hits = phits.view(-1, 4)[:m].cpu().numpy().view(rt.HIT).ravel()
+        g_bhits = bhits.view(-1, 4)[:m].cpu().numpy().view(rt.HIT).ravel()
+        out["cpu_bvh_baseline"] = {"value": round(2 * m / walk_s / 1e6, 3), "unit": "Mrays/s", "cores": oracle.num_threads(),
+                                   "kind": "build CPU BVH, not reference",
+                                   "sample": f"first {m} primary + {m} bounce rays of the frame, BVH2 walk, {walk_s:.1f} s"}
+        out["parity"].update({"bvh_walk_sample_rays": 2 * m,
+                              "bvh_walk_prim_id_mismatches": int((w_hits["prim"] != g_hits["prim"]).sum() + (w_bhits["prim"] != g_bhits["prim"]).sum()),
+                              "bvh_walk_bit_exact": bool(w_hits.tobytes() == g_hits.tobytes() and w_bhits.tobytes() == g_bhits.tobytes())})
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

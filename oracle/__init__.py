@@ -48,6 +48,7 @@ def lib():
             "orc_primary_rays": (None, [P, U32, U32, U32, U32, C.c_int, P]),
             "orc_trace": (None, [P, P, U64, P]),
             "orc_occluded": (None, [P, P, U64, P]),
+            "orc_trace_bvh2": (None, [P, P, U32, P, P, U64, P]),
             "orc_hit_point": (C.c_int, [P, P, P, FP, FP]),
             "orc_shadow_lit": (None, [P, P, P, U64, FP, P, P]),
             "orc_bounce": (None, [P, P, P, U64, U32, P]),
@@ -93,6 +94,19 @@ def trace(scene, rays):
     out = np.empty(len(rays), dtype=HIT)
     if len(rays):
         lib().orc_trace(scene.ref(), _p(rays), len(rays), _p(out))
+    return out
+
+
+def trace_bvh2(scene, nodes, tri_order, rays):
+    """SURVEY 8(d) 'build CPU BVH, not reference': closest hit over a flattened BVH2 (uint32 [n_nodes, 16] as emitted by
+    the product's rt_bvh_build_host, passed in as data) with the oracle's own primitive tests."""
+    rays = np.ascontiguousarray(rays, dtype=RAY)
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    order = np.ascontiguousarray(tri_order, dtype=np.uint32)
+    out = np.empty(len(rays), dtype=HIT)
+    n_nodes = 0 if len(scene.tris) == 0 else len(nodes)
+    if len(rays):
+        lib().orc_trace_bvh2(scene.ref(), _p(nodes), n_nodes, _p(order), _p(rays), len(rays), _p(out))
     return out
 
 

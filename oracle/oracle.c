@@ -134,6 +134,85 @@ void orc_trace(const orc_scene* s, const orc_ray* rays, uint64_t n, orc_hit* out
     for (int64_t i = 0; i < (int64_t)n; ++i) orc_trace_one(s, &rays[i], &out[i]);
 }
 
+/* ---- "build CPU BVH, not reference" (second CPU row) --------------------------------------
+ * The same closest-hit query answered by walking a BVH2 on the CPU: the FAIR CPU figure beside the brute-force one.
+ * `nodes` is the flattened BVH2 the product's host builder emits (rt_bvh_build_host, layout BVH2: 16 words per node,
+ * (c0.lo.x,c0.hi.x,c0.lo.y,c0.hi.y) (c1 ...) (c0.lo.z,c0.hi.z,c1.lo.z,c1.hi.z) (ref0,ref1,-,-); ref >= 0 interior,
+ * ~ref = first<<3 | count-1 a leaf over tri_order[first ..]); it is input data here, the oracle links nothing of the
+ * product.  Triangles are tested with the oracle's own ray_tri on the caller's records; candidates are merged with
+ * the order-independent form of the reference's rule (smaller t, then spheres before triangles, then lower index),
+ * so the result equals orc_trace whenever no accepted triangle's leaf is culled (the boxes are padded for that). */
+static void trace_one_bvh2(const orc_scene* s, const uint32_t* nodes, uint32_t n_nodes, const uint32_t* tri_order,
+                           const orc_ray* r, orc_hit* out) {
+    v3 o = V(r->ox, r->oy, r->oz), d = V(r->dx, r->dy, r->dz);
+    orc_hit best = { r->tmax, 0.0f, 0.0f, ORC_MISS };
+    if (!(r->tmax > r->tmin)) { *out = best; return; }
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const char* sp = (const char*)s->spheres + (size_t)i * s->sphere_stride;
+        float t;
+        if (ray_sphere(o, d, ld3(sp, SPH_C), ldf(sp, SPH_R), &t) && t < best.t && t >= r->tmin) {
+            best.t = t; best.u = 0.0f; best.v = 0.0f; best.prim = ORC_SPHERE_BIT | i;
+        }
+    }
+    if (n_nodes == 0) { *out = best; return; }
+    const float idir[3] = { 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };     /* +-inf for axis-parallel rays: slabs still work */
+    const float org[3] = { o.x, o.y, o.z };
+    const float tmin0 = r->tmin > 0.0f ? r->tmin : 0.0f;
+    int32_t stack[64];
+    int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const float* q = (const float*)(nodes + (size_t)node * 16);
+            const int32_t* refs = (const int32_t*)(nodes + (size_t)node * 16 + 12);
+            float tn[2], tf[2];
+            for (int c = 0; c < 2; ++c) {
+                const float lo[3] = { q[4 * c], q[4 * c + 2], q[8 + 2 * c] }, hi[3] = { q[4 * c + 1], q[4 * c + 3], q[9 + 2 * c] };
+                float a = tmin0, b = best.t;
+                for (int k = 0; k < 3; ++k) {
+                    float t0 = (lo[k] - org[k]) * idir[k], t1 = (hi[k] - org[k]) * idir[k];
+                    if (t0 != t0 || t1 != t1) continue;               /* 0 * inf: the ray lies in the slab plane */
+                    if (t0 > t1) { float x = t0; t0 = t1; t1 = x; }
+                    if (t0 > a) a = t0;
+                    if (t1 < b) b = t1;
+                }
+                tn[c] = a; tf[c] = b;
+            }
+            const int h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1];
+            if (h0 && h1) {
+                const int near = tn[1] < tn[0];
+                stack[sp++] = refs[!near];
+                node = refs[near];
+            } else if (h0 || h1) {
+                node = refs[h1];
+            } else {
+                if (sp == 0) break;
+                node = stack[--sp];
+            }
+        } else {
+            const uint32_t ref = ~(uint32_t)node, first = ref >> 3, cnt = (ref & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t id = tri_order[first + k];
+                const char* tp = (const char*)s->tris + (size_t)id * s->tri_stride;
+                float t, u, v;
+                if (ray_tri(o, d, ld3(tp, TRI_P0), ld3(tp, TRI_P1), ld3(tp, TRI_P2), &t, &u, &v) && t >= r->tmin &&
+                    (t < best.t || (t == best.t && best.prim != ORC_MISS && !(best.prim & ORC_SPHERE_BIT) && id < best.prim))) {
+                    best.t = t; best.u = u; best.v = v; best.prim = id;
+                }
+            }
+            if (sp == 0) break;
+            node = stack[--sp];
+        }
+    }
+    *out = best;
+}
+
+void orc_trace_bvh2(const orc_scene* s, const uint32_t* nodes, uint32_t n_nodes, const uint32_t* tri_order,
+                    const orc_ray* rays, uint64_t n, orc_hit* out) {
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < (int64_t)n; ++i) trace_one_bvh2(s, nodes, n_nodes, tri_order, &rays[i], &out[i]);
+}
+
 /* any-hit: 1 iff some primitive is accepted in [tmin, tmax) -- by construction identical to
  * "closest-hit found something". */
 void orc_occluded(const orc_scene* s, const orc_ray* rays, uint64_t n, uint8_t* out) {

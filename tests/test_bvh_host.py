@@ -122,3 +122,30 @@ def test_build_is_deterministic_across_thread_counts():
     a = rt.bvh_build_host(tris, threads=1)
     b = rt.bvh_build_host(tris, threads=8)
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_cpu_bvh_walk_equals_the_reference_loop():
+    """SURVEY 8(d) second CPU row: the oracle's walk over the product's flattened BVH2 (handed over as data) returns
+    the brute-force reference loop's records bit for bit -- soups, Cornell (incl. KAT-1's tie), rays from outside,
+    axis-parallel rays, intervals.  This also pins the builder: no accepted triangle's leaf may be culled."""
+    import oracle
+    for n_tris, half, leaf in ((1, 0.3, 4), (7, 0.3, 1), (3000, 0.05, 4), (20000, 0.02, 8)):
+        tris = scenes.soup(n_tris, half_extent=half)
+        rays = scenes.random_rays(20000)
+        rays["o"][:5000] = rays["o"][:5000] * 4 - 2
+        rays["d"][5000:5100] = (0.0, 0.0, 1.0)
+        rays["tmax"][::9] = 0.1
+        _, nodes, order = rt.bvh_build_host(tris, layout=rt.TRAVERSAL_BVH2, max_leaf=leaf)
+        sc = oracle.Scene(tris)
+        assert oracle.trace_bvh2(sc, nodes, order, rays).tobytes() == oracle.trace(sc, rays).tobytes(), (n_tris, leaf)
+    tris, sph, _ = scenes.cornell()
+    rays = oracle.primary_rays(rt.default_camera(1.0), 96, 96)
+    kat = np.zeros(1, dtype=rt.RAY); kat["o"], kat["d"], kat["tmax"] = (0, 4, 1), (0, -1, 0), 1e20
+    rays = np.concatenate([rays.ravel(), kat])
+    _, nodes, order = rt.bvh_build_host(tris, layout=rt.TRAVERSAL_BVH2)
+    sc = oracle.Scene(tris, sph)
+    got = oracle.trace_bvh2(sc, nodes, order, rays)
+    assert got.tobytes() == oracle.trace(sc, rays).tobytes()
+    assert got[-1]["prim"] == 2 and got[-1]["t"] == 6.0                      # KAT-1: the tie keeps the lower index
+    assert oracle.trace_bvh2(oracle.Scene(None, sph), np.zeros((0, 16), np.uint32), np.zeros(0, np.uint32), rays).tobytes() == \
+        oracle.trace(oracle.Scene(None, sph), rays).tobytes()
