@@ -9,7 +9,7 @@ every stage on device, nothing skipped:
                     segment 0 of the path loop: emission + Cook-Torrance throughput + cosine-weighted bounce ray
                     (frag.glsl:310-350)
   2. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent)
-  3. k_shade        radiance of the second segment;  k_resolve -> RGBA8 framebuffer (frag.glsl:357-359)
+  3. k_shade_resolve  radiance of the second (last) segment + average, gamma -> RGBA8 framebuffer (frag.glsl:357-359)
   4. N > 1 only: all-gather of the per-rank framebuffer stripes over RCCL/xGMI + de-interleave
 value = closest-hit rays of the whole job / wall time (max over ranks).  With N ranks the frame's 16-row
 stripes are interleaved over the ranks (BVH replicated): total work is fixed, so scaling is "strong".
@@ -115,8 +115,8 @@ def main():
         r.trace_dev(brays, n_local, bhits, stream=stream)
 
     def stage_shade2_resolve():
-        r.shade_stripes_dev(brays, bhits, n_local, thr, rad, None, key0, row_len, STRIPE, world, seed=SEED + 2, stream=stream)
-        r.resolve_dev(rad, n_px, SPP, None, fb, stream=stream)
+        # radiance of the second (last) segment + resolve in one launch: the final radiance stays in registers
+        r.shade_resolve_dev(brays, bhits, n_local, SPP, thr, rad, None, fb, stream=stream)
 
     def stage_gather():
         if world == 1:

@@ -193,6 +193,13 @@ int  rt_primary_shade_stripes_dev(rt_ctx* ctx, int slot, uint32_t w, uint32_t h,
  * d_linear4 (4 floats per pixel, pre-gamma) and d_rgba8 may each be NULL, not both. */
 int  rt_resolve_dev(rt_ctx* ctx, int slot, const float* d_radiance4, uint64_t n_pixels, uint32_t spp,
                     float* d_linear4, uint8_t* d_rgba8, void* stream);
+
+/* Last segment of the path loop + resolve in one launch: rt_shade_stripes_dev(..., d_out = NULL) followed by
+ * rt_resolve_dev (frag.glsl:310-338, :357-359) without the final radiance going through HBM.  n = pixels * spp rays in
+ * (pixel, sample) order.  d_radiance4 is read but NOT updated (with spp not a power of two <= 64 the two separate
+ * kernels run instead and it is).  Same bits as the two calls. */
+int  rt_shade_resolve_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t spp,
+                          float* d_throughput4, float* d_radiance4, float* d_linear4, uint8_t* d_rgba8, void* stream);
 /* The whole of frag.glsl:main for a w x h frame: spp jittered samples per pixel (the reference: 10), `bounces`
  * path segments (the reference: 8), lights as uploaded.  host_rgba8[(y*w+x)*4 ..], row 0 = top.  The RNG is the
  * seeded hash of DESIGN.md (frag.glsl:13-15 is parity-unpinned), sample s of pixel p uses key (p*spp+s). */

@@ -261,6 +261,11 @@ class Renderer:
                                                            _ptr(throughput), _ptr(radiance), _ptr(next_rays),
                                                            _stream_ptr(stream)))
 
+    def shade_resolve_dev(self, rays, hits, n, spp, throughput, radiance, linear=None, rgba8=None, slot=0, stream=None):
+        """Last path segment + resolve in one launch (rt_shade_resolve_dev); `radiance` is read, not updated."""
+        self._check(self._lib.rt_shade_resolve_dev(self._ctx, slot, _ptr(rays), _ptr(hits), n, spp, _ptr(throughput),
+                                                   _ptr(radiance), _ptr(linear), _ptr(rgba8), _stream_ptr(stream)))
+
     def resolve_dev(self, radiance, n_pixels, spp, linear=None, rgba8=None, slot=0, stream=None):
         self._check(self._lib.rt_resolve_dev(self._ctx, slot, _ptr(radiance), n_pixels, spp, _ptr(linear), _ptr(rgba8),
                                              _stream_ptr(stream)))

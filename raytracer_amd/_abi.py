@@ -51,6 +51,7 @@ SYMBOLS = [
     ("rt_shade_dev", _I, [_P, _I, _P, _P, _U64, _U32, _U32, _P, _P, _P, _P]),
     ("rt_shade_stripes_dev", _I, [_P, _I, _P, _P, _U64, _U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P]),
     ("rt_primary_shade_stripes_dev", _I, [_P, _I, _U32, _U32, _U32, _U32, _U32, _U32, _U32, _U32, _I, _U32, _P, _P, _P, _P, _P, _P]),
+    ("rt_shade_resolve_dev", _I, [_P, _I, _P, _P, _U64, _U32, _P, _P, _P, _P, _P]),
     ("rt_resolve_dev", _I, [_P, _I, _P, _U64, _U32, _P, _P, _P]),
     ("rt_render", _I, [_P, _U32, _U32, _U32, _U32, _U32, _P]),
     ("rt_counters_get", _I, [_P, _I, C.POINTER(rt_counters), _I]),

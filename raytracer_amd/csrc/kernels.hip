@@ -802,6 +802,59 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ r
     }
 }
 
+// Last segment of the path loop fused with the resolve (frag.glsl:310-338 + :357-359): a path's final radiance never
+// goes through HBM.  Rays are laid out (pixel, sample) with spp consecutive samples per pixel and spp divides 64, so a
+// pixel's samples sit in adjacent lanes of one wave; its first lane adds them in sample order (the same order, hence
+// the same bits, as k_resolve) and writes the pixel.  d_radiance is read, not updated.
+__device__ __forceinline__ uint32_t to_rgba8(float r, float g, float b) {
+    const float c[3] = { r, g, b };
+    uint32_t px = 0xff000000u;
+    #pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float v = powf(c[a], 1.0f / 2.6f);
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        if (!(v == v)) v = 0.0f;
+        px |= (uint32_t)(v * 255.0f + 0.5f) << (8 * a);
+    }
+    return px;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rt_ray* __restrict__ rays,
+                                                          const float4* __restrict__ hits, uint64_t n, uint32_t spp,
+                                                          const float4* __restrict__ thr, const float4* __restrict__ rad,
+                                                          float4* __restrict__ lin, uint32_t* __restrict__ rgba) {
+    extern __shared__ int stack[];
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    f3 C = mk(0.0f, 0.0f, 0.0f);
+    if (i < n) {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        float4 r0 = rp[0], r1 = rp[1];
+        float4 hit = hits[i];
+        float4 c4 = rad[i];
+        C = mk(c4.x, c4.y, c4.z);
+        if (r1.w > r0.w && __float_as_uint(hit.w) != RT_MISS) {
+            float4 t4 = thr[i];
+            f3 T = mk(t4.x, t4.y, t4.z), o, dir;
+            shade_one<MODE>(s, r0, r1, hit, T, C, 0u, 0u, false, stack + (MODE != kBrute ? threadIdx.x : 0), o, dir);
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, first = lane & ~(spp - 1u);
+    float c[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t k = 0; k < spp; ++k) {                                   // wave-uniform trip count
+        c[0] += __shfl(C.x, (int)(first + k), 64);
+        c[1] += __shfl(C.y, (int)(first + k), 64);
+        c[2] += __shfl(C.z, (int)(first + k), 64);
+    }
+    if (i < n && lane == first) {
+        const uint64_t p = i / spp;
+        const float fs = (float)spp;
+        c[0] = c[0] / fs; c[1] = c[1] / fs; c[2] = c[2] / fs;
+        if (lin) lin[p] = make_float4(c[0], c[1], c[2], 1.0f);
+        if (rgba) rgba[p] = to_rgba8(c[0], c[1], c[2]);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill(float4* __restrict__ d, uint64_t n, float4 v) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) d[i] = v;
@@ -1005,6 +1058,20 @@ hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const
     // the traversal inside k_shade only runs when the scene has lights
     const int m = s.n_lights ? mode : kBrute;
 #define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shade<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, row_len, stripe_h, stripe_step, seed, d_throughput, d_radiance, out)
+    if (m == kBrute) RT_LAUNCH_M(kBrute); else if (m == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
+#undef RT_LAUNCH_M
+    return hipGetLastError();
+}
+
+hipError_t launch_shade_resolve(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                                uint32_t spp, const float4* d_throughput, const float4* d_radiance, float4* d_linear,
+                                uint32_t* d_rgba8, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (spp == 0 || spp > 64 || (spp & (spp - 1)) || n % spp) return hipErrorInvalidValue;
+    dim3 g(grid_for(n)), b(kBlock);
+    const float4* hits = reinterpret_cast<const float4*>(d_hits);
+    const int m = s.n_lights ? mode : kBrute;
+#define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shade_resolve<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, spp, d_throughput, d_radiance, d_linear, d_rgba8)
     if (m == kBrute) RT_LAUNCH_M(kBrute); else if (m == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH_M
     return hipGetLastError();

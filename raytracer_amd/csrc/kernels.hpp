@@ -72,6 +72,10 @@ hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const
 // frag.glsl:357-359: average over spp, gamma 1/2.6, RGBA8 (+ optional linear float4)
 hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t spp, float4* d_linear, uint32_t* d_rgba8,
                           hipStream_t st);
+// last path segment + resolve in one kernel; spp must be a power of two <= 64 that divides n (else hipErrorInvalidValue)
+hipError_t launch_shade_resolve(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
+                                uint32_t spp, const float4* d_throughput, const float4* d_radiance, float4* d_linear,
+                                uint32_t* d_rgba8, hipStream_t st);
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
 
 constexpr int kStackDepth = 32;   // per-lane traversal stack entries held in LDS

@@ -623,6 +623,29 @@ int rt_resolve_dev(rt_ctx* c, int slot, const float* d_radiance4, uint64_t n_pix
     return RT_OK;
 }
 
+int rt_shade_resolve_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t spp,
+                         float* d_throughput4, float* d_radiance4, float* d_linear4, uint8_t* d_rgba8, void* stream) {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (spp == 0 || n % spp) return fail(c, RT_E_INVALID, "shade+resolve: n must be a multiple of spp");
+    if (n && (!d_rays || !d_hits || !d_throughput4 || !d_radiance4 || (!d_linear4 && !d_rgba8)))
+        return fail(c, RT_E_INVALID, "shade+resolve: null device pointer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    hipStream_t st = (hipStream_t)stream;
+    const DevScene ds = c->dev_scene(r);
+    float4* thr = reinterpret_cast<float4*>(d_throughput4);
+    float4* rad = reinterpret_cast<float4*>(d_radiance4);
+    if (spp <= 64 && (spp & (spp - 1)) == 0) {
+        RT_HIP(c, launch_shade_resolve(ds, c->mode(), d_rays, d_hits, n, spp, thr, rad, reinterpret_cast<float4*>(d_linear4),
+                                       reinterpret_cast<uint32_t*>(d_rgba8), st));
+    } else {                                     // samples of a pixel would straddle waves: the two separate kernels
+        RT_HIP(c, launch_shade(ds, c->mode(), d_rays, d_hits, n, 0, 0, 1, 1, 0, thr, rad, nullptr, st));
+        RT_HIP(c, launch_resolve(rad, n / spp, spp, reinterpret_cast<float4*>(d_linear4), reinterpret_cast<uint32_t*>(d_rgba8), st));
+    }
+    return RT_OK;
+}
+
 // frag.glsl:303-360 for a whole frame, as a wavefront pipeline: k_primary, then per bounce k_shade + closest hit.
 int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* host_rgba8) {
     if (!c) return RT_E_INVALID;
@@ -661,12 +684,17 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         const PrimaryShade ps = { thr, rad, bounces > 1 ? ra : nullptr, seed + 1u };
         RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, nullptr, nullptr, r.d_counters, r.stream, &ps));
         const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
+        const bool fuse_last = bounces > 1 && spp <= 64 && (spp & (spp - 1)) == 0;    // last segment + resolve in one kernel
         for (uint32_t b = 1; b < bounces; ++b) {
             RT_HIP_SLOT(r, trace_rays(c, r, false, false, ra, n, hits, nullptr, r.stream));
+            if (b + 1 == bounces && fuse_last) {
+                RT_HIP_SLOT(r, launch_shade_resolve(ds, mode, ra, hits, n, spp, thr, rad, nullptr, rgba, r.stream));
+                break;
+            }
             RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, 0, 1, 1, seed + 1u + b, thr, rad, b + 1 < bounces ? rb : nullptr, r.stream));
             std::swap(ra, rb);
         }
-        RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));
+        if (!fuse_last) RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));
         RT_HIP_SLOT(r, hipMemcpyAsync(host_rgba8 + (size_t)y0 * w * 4, rgba, npx * 4, hipMemcpyDeviceToHost, r.stream));
         RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
         return RT_OK;

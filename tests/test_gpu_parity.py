@@ -520,6 +520,39 @@ def test_fused_primary_shade_equals_the_three_separate_stages(renderer, torch_de
         assert (not with_lights) or float(rad.view(-1, 4)[:, :3].sum()) > 0
 
 
+@pytest.mark.parametrize("with_lights", [False, True])
+@pytest.mark.parametrize("spp", [1, 3, 4, 16])
+def test_fused_last_segment_resolve_equals_the_two_stages(renderer, torch_dev, spp, with_lights):
+    """rt_shade_resolve_dev = rt_shade_dev(out = NULL) + rt_resolve_dev, bit for bit (spp 3: the documented fallback)."""
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(tris, sph, _lights2() if with_lights else None)
+    renderer.update_camera(rt.default_camera(1.0))
+    w, h, seed = 37, 29, 4                          # 37 * 29 * spp rays: ragged last block
+    n = w * h * spp
+    f = lambda k: torch.empty(n * k, dtype=torch.float32, device="cuda")
+    ra, hits, thr, rad, nxt = f(8), f(4), f(4), f(4), f(8)
+    s = torch.cuda.current_stream()
+    renderer.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, nxt, spp=spp, seed=seed, jitter=True, shade_seed=seed + 1, stream=s)
+    renderer.trace_dev(nxt, n, hits, stream=s)
+    lin_a, lin_b = torch.zeros(w * h * 4, device="cuda"), torch.zeros(w * h * 4, device="cuda")
+    px_a, px_b = torch.zeros(w * h, dtype=torch.int32, device="cuda"), torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    rad_b = rad.clone()
+    renderer.shade_resolve_dev(nxt, hits, n, spp, thr, rad, lin_a, px_a, stream=s)
+    renderer.shade_dev(nxt, hits, n, thr, rad_b, None, stream=s)
+    renderer.resolve_dev(rad_b, w * h, spp, lin_b, px_b, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(lin_a.view(torch.int32), lin_b.view(torch.int32))
+    assert torch.equal(px_a, px_b)
+    assert float(lin_a.view(-1, 4)[:, :3].sum()) > 0
+    with pytest.raises(RuntimeError):                # n must be a whole number of pixels; spp 0 is rejected
+        if spp > 1:
+            renderer.shade_resolve_dev(nxt, hits, n - 1, spp, thr, rad, lin_a, px_a)
+        else:
+            renderer.shade_resolve_dev(nxt, hits, n, 0, thr, rad, lin_a, px_a)
+
+
 def test_rt_render_matches_oracle_frame():
     """rt_render (host RGBA8, two replicas on the one GPU = the in-process multi-device path) against orc_render;
     the reference's own SAMPLES/BOUNCES are 10/8 (frag.glsl:3-4), here 4/5 on 96x72 to keep the oracle quick."""
