@@ -57,10 +57,13 @@ enum {
     RT_OPT_STRIP = 6,       /* ray-buffer kernel: rays per chunk a persistent wave draws (default 256); 0 = one ray per lane, no refill */
     RT_OPT_REFILL = 7,      /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 16),
                                bits 8.. = lanes holding a parked leaf before the triangle block runs (default 24) */
-    RT_OPT_RAY_BINNING = 8  /* ray-buffer kernel: hand rays out grouped by origin cell (16^3 Morton grid over the scene,
+    RT_OPT_RAY_BINNING = 8, /* ray-buffer kernel: hand rays out grouped by origin cell (16^3 Morton grid over the scene,
                                dead rays last): 0 off, 1 on, 2 auto = when nodes + triangles exceed 48 MB and the buffer
                                holds >= 2^18 rays (default).  Output order and values are unaffected.  Uses per-slot
                                scratch (4 B per ray): calls on one slot that bin must be stream-ordered. */
+    RT_OPT_LDS_STACK = 9    /* ray-buffer kernel, BVH4q nodes: traversal-stack entries per lane kept in LDS (default 20, 2..64);
+                               deeper entries spill to a per-slot area in HBM, which lets 8 waves per SIMD run instead of
+                               3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected. */
 };
 
 /* Scene / acceleration-structure statistics after rt_scene_upload. */

@@ -20,7 +20,7 @@
 namespace rt {
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = kThreads;
 constexpr float kEps = 1e-6f;              // frag.glsl:131
 constexpr int kDone = (int)0x80000000;   // stack-bottom sentinel (never a valid leaf reference: first tri < 2^28)
 constexpr uint32_t kKeyFlip = 0x80000000u; // tie-break key = prim ^ kKeyFlip: spheres sort before triangles
@@ -179,11 +179,25 @@ __device__ __forceinline__ void cswap(uint32_t& ka, int& ra, uint32_t& kb, int& 
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
-template <bool COUNT>
+// Capped stack of the ray-buffer kernel: the first `cap` entries (RT_OPT_LDS_STACK, default 20) of a lane's stack live in LDS, deeper ones in
+// a per-thread column of a global spill area.  The worst-case depth of a BVH4q (3 pushes per level) is far above
+// what rays use, and sizing LDS for the worst case holds the kernel at 3-4 waves per SIMD; with the cap it runs at 8.
+struct Spill { int* col; size_t stride; int cap; };   // this thread's column, stride = threads of the launch, LDS entries
+__device__ __forceinline__ int st_read(const int* __restrict__ stk, const Spill& sp_, int idx) {
+    return idx < sp_.cap ? stk[idx * kBlock] : sp_.col[(size_t)(idx - sp_.cap) * sp_.stride];
+}
+__device__ __forceinline__ void st_write(int* __restrict__ stk, const Spill& sp_, int idx, int v) {
+    if (idx < sp_.cap) stk[idx * kBlock] = v; else sp_.col[(size_t)(idx - sp_.cap) * sp_.stride] = v;
+}
+
+template <bool COUNT, bool CAPPED = false>
 __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
-                                          int* __restrict__ stk, int& sp, Counters& c) {
+                                          int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0, 0 }) {
     const uint4* np = reinterpret_cast<const uint4*>(nodes) + (size_t)node * 4;
-    const int popped = stk[(sp - 1) * kBlock];
+    // this step touches stack slots sp-1 .. sp+2: all in LDS unless the lane is unusually deep
+    const bool in_lds = !CAPPED || sp + 3 <= spill.cap;
+    int popped;
+    if (in_lds) popped = stk[(sp - 1) * kBlock]; else popped = st_read(stk, spill, sp - 1);
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 q3 = *reinterpret_cast<const uint2*>(np + 3);
     const uint32_t w = q0.w;
@@ -222,9 +236,15 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     cswap(key[1], ref[1], key[2], ref[2]);
     const int h = (key[0] != 0xffffffffu) + (key[1] != 0xffffffffu) + (key[2] != 0xffffffffu) + (key[3] != 0xffffffffu);
     // push hits 1..h-1, farthest first: entry j lands at sp + h - 1 - j
-    if (h > 3) stk[sp * kBlock] = ref[3];
-    if (h > 2) stk[(sp + h - 3) * kBlock] = ref[2];
-    if (h > 1) stk[(sp + h - 2) * kBlock] = ref[1];
+    if (in_lds) {
+        if (h > 3) stk[sp * kBlock] = ref[3];
+        if (h > 2) stk[(sp + h - 3) * kBlock] = ref[2];
+        if (h > 1) stk[(sp + h - 2) * kBlock] = ref[1];
+    } else {
+        if (h > 3) st_write(stk, spill, sp, ref[3]);
+        if (h > 2) st_write(stk, spill, sp + h - 3, ref[2]);
+        if (h > 1) st_write(stk, spill, sp + h - 2, ref[1]);
+    }
     sp += h ? h - 1 : -1;
     return h ? ref[0] : popped;
 }
@@ -244,10 +264,10 @@ __device__ __forceinline__ void bvh2_leaf(const float4* __restrict__ tris, int n
     }
 }
 
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool CAPPED = false>
 __device__ __forceinline__ int bvh_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
-                                        int* __restrict__ stk, int& sp, Counters& c) {
-    if (MODE == kBvh4q) return bvh4q_step<COUNT>(nodes, node, sl, tmin0, bt, stk, sp, c);
+                                        int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0, 0 }) {
+    if (MODE == kBvh4q) return bvh4q_step<COUNT, CAPPED>(nodes, node, sl, tmin0, bt, stk, sp, c, spill);
     return bvh2_step<COUNT>(nodes, node, sl, tmin0, bt, stk, sp, c);
 }
 
@@ -347,12 +367,13 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 // next rays of the chunk (rank by mbcnt over the idle ballot: coalesced reads), while the other lanes keep their
 // traversal state, and a new chunk is drawn as soon as the current one is handed out, so the only tail is the
 // one at the end of the launch.  Each lane writes its hit when it finishes; results do not depend on the order.
-template <int MODE, bool ANY, bool COUNT>
+template <int MODE, bool ANY, bool COUNT, bool CAPPED>
 __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
                                                         unsigned long long* __restrict__ work /* 8 chunk cursors, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
                                                         const uint32_t* __restrict__ perm_on /* device flag, null = on */,
+                                                        int* __restrict__ spill_base /* CAPPED: [entry][thread of the launch] */, int lds_cap,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                         unsigned long long* counters) {
     extern __shared__ int stack[];
@@ -365,6 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     const uint64_t n_chunks = (n + strip - 1) / strip;
     const uint32_t per_q = (uint32_t)((n_chunks + 7) / 8);            // chunks per eighth
     uint32_t q = blockIdx.x & 7u, q_tried = 0;                        // workgroups go round-robin over the 8 XCDs
+    const Spill spill = { CAPPED ? spill_base + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr, (size_t)gridDim.x * kBlock, lds_cap };
     stk[0] = kDone;
     int node = kDone, sp = 1;
     uint64_t my = 0;
@@ -434,8 +456,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
         // (wave-uniform branch) until at least `tth` lanes hold a parked leaf or no lane can walk any further.
         const bool need_i = node >= 0;
         if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); }
-        if (need_i) node = bvh_step<MODE, COUNT>(nodes, node, sl, tmin0, b.t, stk, sp, c);
-        if (node < 0 && node != kDone && pend == 0) { pend = node; --sp; node = stk[sp * kBlock]; }
+        if (need_i) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
+        if (node < 0 && node != kDone && pend == 0) { pend = node; --sp; node = CAPPED ? st_read(stk, spill, sp) : stk[sp * kBlock]; }
         const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);
         if (__popcll(mt) >= tth || __ballot(node >= 0) == 0ull) {
@@ -957,6 +979,8 @@ inline int num_cus() {                        // of the current device (cached p
 
 }  // namespace
 
+int device_cus() { return num_cus(); }
+
 hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st) {
     if (n == 0) return hipSuccess;
     if (n >= (1ull << 32)) return hipErrorInvalidValue;
@@ -977,7 +1001,7 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
-                        uint32_t strip, int refill, const uint32_t* d_perm, const uint32_t* d_perm_on) {
+                        uint32_t strip, int refill, const uint32_t* d_perm, const uint32_t* d_perm_on, int* d_spill, int lds_cap) {
     if (n == 0) return hipSuccess;
     dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
@@ -989,20 +1013,24 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         unsigned long long* work = d_counters + kNumCounters + (size_t)(seq.fetch_add(1) % kWorkSlots) * 8;
         hipError_t e = hipMemsetAsync(work, 0, 8 * sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;
-        const size_t lds = stack_bytes(s, mode);
+        const bool capped = mode == kBvh4q && d_spill && lds_cap >= 2 && s.stack_depth + 2 > (uint32_t)lds_cap;
+        const size_t lds = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
         const uint64_t n_chunks = (n + strip - 1) / strip;
         const uint64_t blocks = std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus());
         dim3 g((uint32_t)blocks);
-#define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace_strip<M, A, C>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, hits, d_occ, d_counters)
-#define RT_LAUNCH_M(M) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true); else RT_LAUNCH(M, true, false); } \
-                            else         { if (count) RT_LAUNCH(M, false, true); else RT_LAUNCH(M, false, false); } } while (0)
-        if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
+#define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
+#define RT_LAUNCH_M(M, P) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P); else RT_LAUNCH(M, true, false, P); } \
+                               else         { if (count) RT_LAUNCH(M, false, true, P); else RT_LAUNCH(M, false, false, P); } } while (0)
+        if (mode == kBvh4q) { if (capped) RT_LAUNCH_M(kBvh4q, true); else RT_LAUNCH_M(kBvh4q, false); } else RT_LAUNCH_M(kBvh2, false);
 #undef RT_LAUNCH
+#undef RT_LAUNCH_M
         return hipGetLastError();
     }
     dim3 g(grid_for(n));
 #define RT_LAUNCH(M, A, C) hipLaunchKernelGGL((k_trace<M, A, C>), g, b, stack_bytes(s, M), st, s, d_rays, n, hits, d_occ, d_counters)
+#define RT_LAUNCH_M(M) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true); else RT_LAUNCH(M, true, false); } \
+                            else         { if (count) RT_LAUNCH(M, false, true); else RT_LAUNCH(M, false, false); } } while (0)
     if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_M

@@ -48,7 +48,17 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
                         uint32_t strip /* rays per chunk, 0 = one ray per lane */, int refill /* idle lanes that trigger a refill */,
                         const uint32_t* d_perm = nullptr /* order in which rays are handed out (strip kernel only) */,
-                        const uint32_t* d_perm_on = nullptr /* device flag: 0 = ignore d_perm */);
+                        const uint32_t* d_perm_on = nullptr /* device flag: 0 = ignore d_perm */,
+                        int* d_spill = nullptr /* strip kernel, BVH4q: spill_words() ints; enables the capped LDS stack */,
+                        int lds_cap = 0 /* stack entries kept in LDS when d_spill is given */);
+
+// Capped LDS stack of the strip kernel (kernels.hip "Capped stack"): entries beyond lds_cap spill to global memory,
+// one column per thread of the persistent grid (at most 8 blocks of kThreads per CU).
+constexpr int kThreads = 256;
+inline uint64_t spill_words(uint32_t stack_depth, int lds_cap, int cus) {
+    return stack_depth + 2 > (uint32_t)lds_cap ? (uint64_t)(stack_depth + 2 - lds_cap) * 8u * (uint64_t)cus * kThreads : 0;
+}
+int device_cus();          // multiprocessors of the current device
 
 // With `shade` the first segment of the path loop runs in the same kernel (throughput 1, radiance 0 going in):
 // d_throughput / d_radiance are written for every local ray slot, d_next (may be null) receives the bounce rays,

@@ -45,6 +45,8 @@ struct Replica {
     void* d_out = nullptr;   size_t out_cap = 0;
     // scratch for ray binning (permutation + histograms, uint32 words)
     uint32_t* d_bin = nullptr; uint64_t bin_cap = 0;
+    // spill area of the strip kernel's capped stack: kSpillSlots buffers used round-robin (launches in flight)
+    int* d_spill = nullptr; uint64_t spill_cap = 0; uint32_t spill_seq = 0;
     std::string err;
 };
 
@@ -66,6 +68,7 @@ struct rt_ctx {
     int max_leaf = 4;
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
+    int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
     int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
     BinGrid bin_grid{};         // 16^3 grid over the triangle bounds of the uploaded scene
     // scene
@@ -121,6 +124,7 @@ void free_scene(Replica& r) {
 // (launch_bin), which keeps a wave's node fetches close together when the structure does not fit the L2s.
 constexpr uint64_t kBinMinRays = 1ull << 18;
 constexpr uint64_t kBinMinSceneBytes = 48ull << 20;
+constexpr uint32_t kSpillSlots = 4;       // strip launches of one slot that may be in flight at once
 constexpr uint32_t kBinMinRun = 128;      // mean rays per non-empty (64 Ki-ray block, cell) pair above which a buffer counts as coherent
 hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
                       uint8_t* d_occ, hipStream_t st) {
@@ -143,8 +147,22 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         if (e != hipSuccess) return e;
         perm = r.d_bin;
     }
+    int* spill = nullptr;
+    if (mode == kBvh4q && c->strip >= 64) {
+        const uint64_t words = c->lds_stack ? spill_words(c->stack_need, c->lds_stack, device_cus()) : 0;
+        if (words) {
+            if (words * kSpillSlots > r.spill_cap) {
+                if (r.d_spill) (void)hipFree(r.d_spill);
+                r.d_spill = nullptr; r.spill_cap = 0;
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&r.d_spill), words * kSpillSlots * sizeof(int));
+                if (e != hipSuccess) return e;
+                r.spill_cap = words * kSpillSlots;
+            }
+            spill = r.d_spill + (uint64_t)(r.spill_seq++ % kSpillSlots) * words;
+        }
+    }
     return launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm,
-                        perm ? bin_flag(perm, n) : nullptr);
+                        perm ? bin_flag(perm, n) : nullptr, spill, c->lds_stack);
 }
 
 bool valid_slot(const rt_ctx* c, int slot) { return c && slot >= 0 && slot < (int)c->reps.size(); }
@@ -217,6 +235,7 @@ void rt_destroy(rt_ctx* c) {
         if (r.d_rays) (void)hipFree(r.d_rays);
         if (r.d_out) (void)hipFree(r.d_out);
         if (r.d_bin) (void)hipFree(r.d_bin);
+        if (r.d_spill) (void)hipFree(r.d_spill);
         if (r.d_render) (void)hipFree(r.d_render);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
@@ -234,6 +253,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) {
         case RT_OPT_TRAVERSAL:   if (v < 0 || v > 3) return fail(c, RT_E_INVALID, "RT_OPT_TRAVERSAL: 0 auto, 1 brute, 2 BVH2, 3 BVH4q"); c->traversal = (int)v; return RT_OK;
         case RT_OPT_BVH_THREADS: if (v < 0 || v > 256) return fail(c, RT_E_INVALID, "RT_OPT_BVH_THREADS out of range"); c->bvh_threads = (int)v; return RT_OK;
         case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
+        case RT_OPT_LDS_STACK:   if (v != 0 && (v < 2 || v > 64)) return fail(c, RT_E_INVALID, "RT_OPT_LDS_STACK: 0 or 2..64 entries"); c->lds_stack = (int)v; return RT_OK;
         case RT_OPT_RAY_BINNING: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_RAY_BINNING: 0 off, 1 on, 2 auto"); c->binning = (int)v; return RT_OK;
         case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
         case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;

@@ -8,7 +8,7 @@ from raytracer_amd import scenes
 ap = argparse.ArgumentParser()
 ap.add_argument("--soup", type=int, default=10_000_000); ap.add_argument("--rays", type=int, default=64 << 20)
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--traversal", type=int, default=rt.TRAVERSAL_BVH)
-ap.add_argument("--strip", type=int, default=-1); ap.add_argument("--refill", type=int, default=-1); ap.add_argument("--leaf", type=int, default=-1); ap.add_argument("--binning", type=int, default=-1)
+ap.add_argument("--strip", type=int, default=-1); ap.add_argument("--refill", type=int, default=-1); ap.add_argument("--leaf", type=int, default=-1); ap.add_argument("--binning", type=int, default=-1); ap.add_argument("--cap", type=int, default=-1)
 a = ap.parse_args()
 tris = scenes.soup(a.soup); rays_np = scenes.random_rays(a.rays)
 dev = torch.device("cuda", 0)
@@ -17,6 +17,7 @@ hits = torch.empty(a.rays * 4, dtype=torch.float32, device=dev)
 r = rt.Renderer((0,)); r.set_option(rt.OPT_TRAVERSAL, a.traversal)
 if a.leaf > 0: r.set_option(rt.OPT_MAX_LEAF, a.leaf)
 if a.strip >= 0: r.set_option(rt.OPT_STRIP, a.strip)
+if a.cap >= 0: r.set_option(rt.OPT_LDS_STACK, a.cap)
 if a.binning >= 0: r.set_option(rt.OPT_RAY_BINNING, a.binning)
 if a.refill >= 0: r.set_option(rt.OPT_REFILL, a.refill)
 st = r.create_data(tris)

@@ -271,6 +271,32 @@ def test_ray_binning_changes_the_order_not_the_answer(renderer, torch_dev):
     assert renderer.trace(rays).tobytes() == out[0][0].tobytes()
 
 
+def test_capped_lds_stack_with_spill_changes_nothing(renderer, torch_dev):
+    """RT_OPT_LDS_STACK: the ray-buffer kernel keeps only the first entries of a lane's stack in LDS and spills deeper ones
+    to HBM.  Caps 2 and 3 force nearly every push through the spill path; every cap must give the uncapped records."""
+    n = 150001
+    st, rays = scenes.soup(40000, half_extent=0.03), scenes.random_rays(n)
+    rays["tmax"][::13] = 0.2
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH4Q)
+    renderer.create_data(st)
+    d_rays = to_dev(torch_dev, rays)
+    ref = None
+    for cap in (0, 2, 3, 7, 16, 64):
+        renderer.set_option(rt.OPT_LDS_STACK, cap)
+        hits, occ = dev_buf(torch_dev, n, 16), torch_dev.zeros(n, dtype=torch_dev.uint8, device="cuda")
+        renderer.trace_dev(d_rays, n, hits)
+        renderer.occluded_dev(d_rays, n, occ)
+        torch_dev.cuda.synchronize()
+        got = (to_np(hits, rt.HIT).tobytes(), occ.cpu().numpy().tobytes())
+        if ref is None:
+            ref = got
+            idx = np.sort(np.random.default_rng(5).choice(n, 2048, replace=False))
+            assert_parity(to_np(hits, rt.HIT)[idx], oracle.trace(oracle.Scene(st), rays[idx]), "uncapped soup sample vs oracle")
+        assert got == ref, f"cap {cap}"
+    with pytest.raises(RuntimeError):
+        renderer.set_option(rt.OPT_LDS_STACK, 1)
+
+
 def test_two_slots_on_one_device_equal_one_slot():
     st, rays = scenes.soup(5000, half_extent=0.05), scenes.random_rays(10001)
     tris, sph, _ = scenes.cornell()
