@@ -233,7 +233,7 @@ def main():
     }
 
     # ---- CPU baseline (oracle = reference semantics, brute force) + parity gate on the same sample --------
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:       # the CPU legs run on rank 0 at N = 1 only
         import oracle
         torch.cuda.synchronize()
         live = plan.local_stripes * STRIPE * W * SPP if world > 1 else W * H * SPP
