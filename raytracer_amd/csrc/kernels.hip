@@ -883,7 +883,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(float4* __restrict__ d, uint64_
 }
 
 // ---- ray binning ------------------------------------------------------------------------------------------
-// Counting sort of ray INDICES by origin cell (kernels.hpp), three launches, no global atomics: per-block
+// Counting sort of ray INDICES by origin cell (kernels.hpp), four launches, no global atomics: per-block
 // histograms -> per-(block, bin) bases -> scatter with LDS cursors.  Rays of one bin keep no particular order.
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return (x & 1u) | ((x & 2u) << 2) | ((x & 4u) << 4) | ((x & 8u) << 6); }
 __device__ __forceinline__ uint32_t ray_bin(const rt_ray* __restrict__ rays, uint64_t i, const BinGrid& g) {

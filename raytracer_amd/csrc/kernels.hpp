@@ -88,7 +88,7 @@ hipError_t launch_shade_resolve(const DevScene& s, int mode, const rt_ray* d_ray
                                 uint32_t* d_rgba8, hipStream_t st);
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
 
-constexpr int kStackDepth = 32;   // per-lane traversal stack entries held in LDS
+constexpr int kStackDepth = 32;   // BVH2 depth budget + 2: bounds the per-lane traversal stack of the BVH2 layout
 constexpr int kWorkSlots = 64;    // ring of chunk-cursor sets (8 cursors each) of the strip kernel, stored behind the counters (one set per launch in flight)
 constexpr int kNumCounters = 8;   // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves
 

@@ -61,7 +61,7 @@ struct rt_ctx {
     std::vector<Replica> reps;
     std::string err;
     // options
-    int traversal = 0;          // 0 auto, 1 brute, 2 bvh
+    int traversal = 0;          // 0 auto, 1 brute force, 2 BVH2 nodes, 3 BVH4q nodes (RT_OPT_TRAVERSAL)
     int bvh_threads = 0;
     int counters = 0;
     int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2
