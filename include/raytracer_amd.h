@@ -61,9 +61,13 @@ enum {
                                dead rays last): 0 off, 1 on, 2 auto = when nodes + triangles exceed 48 MB and the buffer
                                holds >= 2^18 rays (default).  Output order and values are unaffected.  Uses per-slot
                                scratch (4 B per ray): calls on one slot that bin must be stream-ordered. */
-    RT_OPT_LDS_STACK = 9    /* ray-buffer kernel, BVH4q nodes: traversal-stack entries per lane kept in LDS (default 20, 2..64);
+    RT_OPT_LDS_STACK = 9,   /* ray-buffer kernel, BVH4q nodes: traversal-stack entries per lane kept in LDS (default 20, 2..64);
                                deeper entries spill to a per-slot area in HBM, which lets 8 waves per SIMD run instead of
                                3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected. */
+    RT_OPT_PRIMARY = 10     /* primary rays: 1 = tile kernel (8x8 pixels per wave, generation fused with traversal and, in
+                               rt_primary_shade_stripes_dev, with the first shading segment); 2 = ray generation into a
+                               buffer + the ray-buffer kernel (+ the first-segment shade); 0 auto = 2 when nodes +
+                               triangles exceed 48 MB, else 1 (default).  Same rays, hits and path state either way. */
 };
 
 /* Scene / acceleration-structure statistics after rt_scene_upload. */

@@ -38,7 +38,7 @@ RAY = np.dtype([("o", "3f4"), ("tmin", "f4"), ("d", "3f4"), ("tmax", "f4")])
 HIT = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("prim", "u4")])
 assert RAY.itemsize == 32 and HIT.itemsize == 16
 
-OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING, OPT_LDS_STACK = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING, OPT_LDS_STACK, OPT_PRIMARY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
 TRAVERSAL_BVH = TRAVERSAL_BVH4Q
 

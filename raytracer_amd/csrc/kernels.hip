@@ -671,8 +671,9 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
         f3 o = mk(cam.px, cam.py, cam.pz);
         const float tmin = 0.0f, tmax = 1e20f;                        // :266
         Best b;
-        int* stk = stack + (MODE != kBrute ? threadIdx.x : 0);
-        trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stk);
+        int* stk = stack + (MODE == kBvh2 || MODE == kBvh4q ? threadIdx.x : 0);
+        if (MODE != kNone) trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stk);
+        else { b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u; }       // ray generation only
         const size_t r = ((size_t)yl * w + x) * spp + smp;
         const float4 r0 = make_float4(o.x, o.y, o.z, tmin), r1 = make_float4(d.x, d.y, d.z, tmax), hit = pack_hit(b, tmax);
         if (rays_out) { rays_out[2 * r] = r0; rays_out[2 * r + 1] = r1; }
@@ -764,7 +765,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __r
     out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
 }
 
-template <int MODE>
+// FIRST: segment 0 of a path -- throughput 1 and radiance 0 are implied (frag.glsl:306-307) instead of read, and both
+// buffers are written for every ray slot, dead ones included (what k_primary<SHADE> does in one kernel).
+template <int MODE, bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
                                                   const float4* __restrict__ hits, uint64_t n, uint32_t key0,
                                                   uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step,
@@ -782,17 +785,26 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __re
         const uint32_t yl = (uint32_t)(i / row_len), rem = (uint32_t)(i - (uint64_t)yl * row_len);
         key = key0 + ((yl / stripe_h) * stripe_h * stripe_step + yl % stripe_h) * row_len + rem;
     }
-    float4 t4 = make_float4(0, 0, 0, 0), c4 = make_float4(0, 0, 0, 0);
+    float4 t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), c4 = make_float4(0, 0, 0, 0);
     const bool alive = r1.w > r0.w && __float_as_uint(hit.w) != RT_MISS;
-    if (alive) { t4 = thr[i]; c4 = rad[i]; }
+    if (!FIRST && alive) { t4 = thr[i]; c4 = rad[i]; }
     f3 T = mk(t4.x, t4.y, t4.z), C = mk(c4.x, c4.y, c4.z), o, dir;
-    if (!shade_one<MODE>(s, r0, r1, hit, T, C, key, seed, out != nullptr, stack + (MODE != kBrute ? threadIdx.x : 0), o, dir)) {
+    const bool go = shade_one<MODE>(s, r0, r1, hit, T, C, key, seed, out != nullptr, stack + (MODE != kBrute ? threadIdx.x : 0), o, dir);
+    if (FIRST) {
+        thr[i] = make_float4(T.x, T.y, T.z, 0.0f);
+        rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
+    }
+    if (!go) {
         if (out) { out[2 * i] = make_float4(0, 0, 0, 0); out[2 * i + 1] = make_float4(0, 0, 0, 0); }
         return;
     }
-    rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
-    if (out == nullptr) return;
-    thr[i] = make_float4(T.x, T.y, T.z, 0.0f);
+    if (FIRST) {
+        if (out == nullptr) return;
+    } else {
+        rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
+        if (out == nullptr) return;
+        thr[i] = make_float4(T.x, T.y, T.z, 0.0f);
+    }
     out[2 * i] = make_float4(o.x, o.y, o.z, 0.0f);
     out[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 1e20f);
 }
@@ -1043,7 +1055,8 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
                           unsigned long long* d_counters, hipStream_t st, const PrimaryShade* shade) {
     if (rows == 0 || w == 0 || spp == 0) return hipSuccess;
     if (stripe_h == 0 || stripe_step == 0) return hipErrorInvalidValue;
-    if (!shade && !d_hits) return hipErrorInvalidValue;
+    if (mode == kNone && (shade || count || !d_rays_out)) return hipErrorInvalidValue;      // kNone: ray generation only
+    if (mode != kNone && !shade && !d_hits) return hipErrorInvalidValue;
     if (shade && (!shade->d_throughput || !shade->d_radiance)) return hipErrorInvalidValue;
     const uint32_t tiles_x = (w + 7) / 8, tiles_y = (rows + 7) / 8;
     const uint64_t n_waves64 = (uint64_t)tiles_x * tiles_y * spp;
@@ -1057,7 +1070,8 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
 #define RT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_primary<M, C, S>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                               jitter, tiles_x, n_waves, rays, hits, d_counters, so)
 #define RT_LAUNCH_M(M) do { if (shade) RT_LAUNCH(M, false, true); else if (count) RT_LAUNCH(M, true, false); else RT_LAUNCH(M, false, false); } while (0)
-    if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
+    if (mode == kNone) hipLaunchKernelGGL((k_primary<kNone, false, false>), g, b, 0, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays, nullptr, d_counters, so);
+    else if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_M
     return hipGetLastError();
@@ -1077,7 +1091,7 @@ hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, cons
 
 hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
                         uint32_t key0, uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed,
-                        float4* d_throughput, float4* d_radiance, rt_ray* d_out, hipStream_t st) {
+                        float4* d_throughput, float4* d_radiance, rt_ray* d_out, hipStream_t st, bool first) {
     if (n == 0) return hipSuccess;
     if (row_len && (stripe_h == 0 || stripe_step == 0)) return hipErrorInvalidValue;
     dim3 g(grid_for(n)), b(kBlock);
@@ -1085,7 +1099,8 @@ hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const
     float4* out = reinterpret_cast<float4*>(d_out);
     // the traversal inside k_shade only runs when the scene has lights
     const int m = s.n_lights ? mode : kBrute;
-#define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shade<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, row_len, stripe_h, stripe_step, seed, d_throughput, d_radiance, out)
+#define RT_LAUNCH_M(M) do { if (first) hipLaunchKernelGGL((k_shade<M, true>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, row_len, stripe_h, stripe_step, seed, d_throughput, d_radiance, out); \
+                            else       hipLaunchKernelGGL((k_shade<M, false>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, key0, row_len, stripe_h, stripe_step, seed, d_throughput, d_radiance, out); } while (0)
     if (m == kBrute) RT_LAUNCH_M(kBrute); else if (m == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH_M
     return hipGetLastError();

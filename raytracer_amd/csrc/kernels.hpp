@@ -27,7 +27,7 @@ struct DevCamera {
     float fx, fy, fz, pad1;
 };
 
-enum TraceMode { kBrute = 1, kBvh2 = 2, kBvh4q = 3 };
+enum TraceMode { kNone = 0 /* launch_primary only: generate the rays, trace nothing */, kBrute = 1, kBvh2 = 2, kBvh4q = 3 };
 
 // Ray binning (order in which the strip kernel hands rays out; results do not depend on it): origins are
 // quantised to a 16^3 grid over the scene bounds, cells in Morton order, dead rays (tmax <= tmin) last.
@@ -78,7 +78,8 @@ hipError_t launch_bounce(const DevScene& s, const rt_ray* d_rays, const rt_hit* 
 // frag.glsl:310-354, one bounce of the path loop for a batch (emission, direct light, next ray, throughput)
 hipError_t launch_shade(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
                         uint32_t key0, uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed,
-                        float4* d_throughput, float4* d_radiance, rt_ray* d_out, hipStream_t st);
+                        float4* d_throughput, float4* d_radiance, rt_ray* d_out, hipStream_t st,
+                        bool first = false /* segment 0: throughput 1 / radiance 0 implied, both written for every slot */);
 // frag.glsl:357-359: average over spp, gamma 1/2.6, RGBA8 (+ optional linear float4)
 hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t spp, float4* d_linear, uint32_t* d_rgba8,
                           hipStream_t st);

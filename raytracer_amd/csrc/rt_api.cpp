@@ -47,6 +47,8 @@ struct Replica {
     uint32_t* d_bin = nullptr; uint64_t bin_cap = 0;
     // spill area of the strip kernel's capped stack: kSpillSlots buffers used round-robin (launches in flight)
     int* d_spill = nullptr; uint64_t spill_cap = 0; uint32_t spill_seq = 0;
+    // primary rays / hits of the ray-buffer primary path when the caller does not ask for them
+    void* d_prim = nullptr; size_t prim_cap = 0;
     std::string err;
 };
 
@@ -69,6 +71,7 @@ struct rt_ctx {
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
     int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
+    int primary_path = 0;       // primary rays: 0 auto, 1 tile kernel (k_primary), 2 ray generation + ray-buffer kernel
     int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
     BinGrid bin_grid{};         // 16^3 grid over the triangle bounds of the uploaded scene
     // scene
@@ -165,6 +168,32 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
                         perm ? bin_flag(perm, n) : nullptr, spill, c->lds_stack);
 }
 
+// Primary rays of a big tree go through the ray-buffer kernel (ray generation -> k_trace_strip): the tile kernel sizes
+// LDS for the tree's worst-case stack and walks each ray to the end (C5: 50 ms against 17 ms); on cache-resident
+// scenes the tile kernel is the faster one (C3: 2.7 against 3.7 ms).  Same rays, same hits either way.
+bool primary_via_buffer(const rt_ctx* c) {
+    const int mode = c->mode();
+    if (mode == kBrute || c->strip < 64 || c->counters || c->primary_path == 1) return false;
+    if (c->primary_path == 2) return true;
+    return (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48 > kBinMinSceneBytes;
+}
+
+// rays (32 B) and / or hits (16 B) for n local ray slots from the slot's scratch when the caller passes none
+hipError_t primary_scratch(Replica& r, uint64_t n, rt_ray** rays, rt_hit** hits) {
+    const size_t need = (size_t)n * ((*rays ? 0 : sizeof(rt_ray)) + (*hits ? 0 : sizeof(rt_hit)));
+    if (need > r.prim_cap) {
+        if (r.d_prim) (void)hipFree(r.d_prim);
+        r.d_prim = nullptr; r.prim_cap = 0;
+        hipError_t e = hipMalloc(&r.d_prim, need);
+        if (e != hipSuccess) return e;
+        r.prim_cap = need;
+    }
+    char* p = static_cast<char*>(r.d_prim);
+    if (!*rays) { *rays = reinterpret_cast<rt_ray*>(p); p += (size_t)n * sizeof(rt_ray); }
+    if (!*hits) *hits = reinterpret_cast<rt_hit*>(p);
+    return hipSuccess;
+}
+
 bool valid_slot(const rt_ctx* c, int slot) { return c && slot >= 0 && slot < (int)c->reps.size(); }
 
 // Run fn(slot) on every replica; one host thread per replica when there are several (they drive
@@ -236,6 +265,7 @@ void rt_destroy(rt_ctx* c) {
         if (r.d_out) (void)hipFree(r.d_out);
         if (r.d_bin) (void)hipFree(r.d_bin);
         if (r.d_spill) (void)hipFree(r.d_spill);
+        if (r.d_prim) (void)hipFree(r.d_prim);
         if (r.d_render) (void)hipFree(r.d_render);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
@@ -254,6 +284,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) {
         case RT_OPT_BVH_THREADS: if (v < 0 || v > 256) return fail(c, RT_E_INVALID, "RT_OPT_BVH_THREADS out of range"); c->bvh_threads = (int)v; return RT_OK;
         case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
         case RT_OPT_LDS_STACK:   if (v != 0 && (v < 2 || v > 64)) return fail(c, RT_E_INVALID, "RT_OPT_LDS_STACK: 0 or 2..64 entries"); c->lds_stack = (int)v; return RT_OK;
+        case RT_OPT_PRIMARY:     if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_PRIMARY: 0 auto, 1 tile kernel, 2 ray-buffer kernel"); c->primary_path = (int)v; return RT_OK;
         case RT_OPT_RAY_BINNING: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_RAY_BINNING: 0 off, 1 on, 2 auto"); c->binning = (int)v; return RT_OK;
         case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
         case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;
@@ -527,6 +558,16 @@ int rt_trace_primary_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, ui
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
+    if (primary_via_buffer(c)) {
+        const uint64_t n = (uint64_t)rows * w * spp;
+        rt_ray* rays = d_rays_out;
+        rt_hit* hits = d_hits_out;
+        RT_HIP(c, primary_scratch(r, n, &rays, &hits));
+        RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, kNone, false, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter,
+                                 rays, nullptr, r.d_counters, st));
+        RT_HIP(c, trace_rays(c, r, false, false, rays, n, hits, nullptr, st));
+        return RT_OK;
+    }
     RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), c->counters != 0, w, h, y0, rows, stripe_h, stripe_step,
                              spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st));
     return RT_OK;
@@ -544,6 +585,19 @@ int rt_primary_shade_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, ui
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
+    if (primary_via_buffer(c)) {
+        const uint64_t n = (uint64_t)rows * w * spp;
+        rt_ray* rays = d_rays_out;
+        rt_hit* hits = d_hits_out;
+        RT_HIP(c, primary_scratch(r, n, &rays, &hits));
+        const DevScene ds = c->dev_scene(r);
+        RT_HIP(c, launch_primary(ds, c->cam, kNone, false, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, rays, nullptr,
+                                 r.d_counters, st));
+        RT_HIP(c, trace_rays(c, r, false, false, rays, n, hits, nullptr, st));
+        RT_HIP(c, launch_shade(ds, c->mode(), rays, hits, n, (uint32_t)((uint64_t)y0 * w * spp), w * spp, stripe_h, stripe_step, shade_seed,
+                               reinterpret_cast<float4*>(d_throughput4), reinterpret_cast<float4*>(d_radiance4), d_next_out, st, true));
+        return RT_OK;
+    }
     const PrimaryShade ps = { reinterpret_cast<float4*>(d_throughput4), reinterpret_cast<float4*>(d_radiance4), d_next_out, shade_seed };
     RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), false, w, h, y0, rows, stripe_h, stripe_step,
                              spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st, &ps));
@@ -701,9 +755,15 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         uint32_t* rgba = reinterpret_cast<uint32_t*>(base + n * 112);
         const DevScene ds = c->dev_scene(r);
         // segment 0: primary rays + their shading in one kernel (the primary rays and hits stay in registers)
-        const PrimaryShade ps = { thr, rad, bounces > 1 ? ra : nullptr, seed + 1u };
-        RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, nullptr, nullptr, r.d_counters, r.stream, &ps));
         const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
+        if (primary_via_buffer(c)) {             // big tree: ray generation -> ray-buffer kernel -> first-segment shade
+            RT_HIP_SLOT(r, launch_primary(ds, c->cam, kNone, false, w, h, y0, rows, rows, 1, spp, seed, 1, rb, nullptr, r.d_counters, r.stream));
+            RT_HIP_SLOT(r, trace_rays(c, r, false, false, rb, n, hits, nullptr, r.stream));
+            RT_HIP_SLOT(r, launch_shade(ds, mode, rb, hits, n, key0, 0, 1, 1, seed + 1u, thr, rad, bounces > 1 ? ra : nullptr, r.stream, true));
+        } else {
+            const PrimaryShade ps = { thr, rad, bounces > 1 ? ra : nullptr, seed + 1u };
+            RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, nullptr, nullptr, r.d_counters, r.stream, &ps));
+        }
         const bool fuse_last = bounces > 1 && spp <= 64 && (spp & (spp - 1)) == 0;    // last segment + resolve in one kernel
         for (uint32_t b = 1; b < bounces; ++b) {
             RT_HIP_SLOT(r, trace_rays(c, r, false, false, ra, n, hits, nullptr, r.stream));

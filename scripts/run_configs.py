@@ -165,17 +165,18 @@ def c5(n_tris):
 
         def frame(count=False):
             a, b = ra, rb
-            r.path_init_dev(n, thr, rad)
-            r.trace_primary_dev(w, h, hits, a, spp=spp, seed=1, jitter=True)
-            for k in range(bounces):
+            r.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, a, spp=spp, seed=1, jitter=True, shade_seed=2)
+            if count:
+                live.append(n)
+            for k in range(1, bounces):
                 if count:
                     live.append(int((a.view(-1, 8)[:, 7] > 0).sum()))
-                last = k + 1 == bounces
-                r.shade_dev(a, hits, n, thr, rad, None if last else b, key0=0, seed=2 + k)
-                if not last:
-                    r.trace_dev(b, n, hits)
+                r.trace_dev(a, n, hits)
+                if k + 1 == bounces:
+                    r.shade_resolve_dev(a, hits, n, spp, thr, rad, None, fb)
+                else:
+                    r.shade_dev(a, hits, n, thr, rad, b, key0=0, seed=2 + k)
                     a, b = b, a
-            r.resolve_dev(rad, w * h, spp, None, fb)
         frame(True); torch.cuda.synchronize()
         ms = timeit(frame, 2)
         traced = sum(live)

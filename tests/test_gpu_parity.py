@@ -579,6 +579,46 @@ def test_fused_last_segment_resolve_equals_the_two_stages(renderer, torch_dev, s
             renderer.shade_resolve_dev(nxt, hits, n, 0, thr, rad, lin_a, px_a)
 
 
+@pytest.mark.parametrize("with_lights", [False, True])
+def test_primary_through_the_ray_buffer_kernel_equals_the_tile_kernel(renderer, torch_dev, with_lights):
+    """RT_OPT_PRIMARY: 1 = tile kernel, 2 = ray generation + ray-buffer kernel (+ first-segment shade), what big trees
+    get automatically.  Rays, hits, throughput, radiance and bounce rays must not differ by a bit; also with a striped
+    share that has a padding stripe, and without the optional ray / hit outputs (library scratch)."""
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    extra = scenes.soup(3000, half_extent=0.05)
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(scenes.cat([tris, extra]), sph, _lights2() if with_lights else None)
+    renderer.update_camera(rt.default_camera(52 / 40))
+    w, h, spp, seed = 52, 40, 4, 6
+    s = torch.cuda.current_stream()
+    for world, rank, sh in ((1, 0, 8), (3, 2, 8)):
+        p = rd.stripe_plan(h, world, rank, sh)
+        n = p.padded_rows * w * spp
+        f = lambda k: torch.full((n * k,), 3.0, dtype=torch.float32, device="cuda")
+        got = {}
+        for path in (1, 2):
+            renderer.set_option(rt.OPT_PRIMARY, path)
+            ra, hits, ra2, hits2, thr, rad, nxt, thr3, rad3, nxt3 = f(8), f(4), f(8), f(4), f(4), f(4), f(8), f(4), f(4), f(8)
+            renderer.trace_primary_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, hits, ra, spp=spp, seed=seed, jitter=True, stream=s)
+            renderer.primary_shade_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, thr, rad, nxt, spp=spp, seed=seed,
+                                               jitter=True, shade_seed=seed + 1, rays=ra2, hits=hits2, stream=s)
+            renderer.primary_shade_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, thr3, rad3, nxt3, spp=spp, seed=seed,
+                                               jitter=True, shade_seed=seed + 1, stream=s)
+            hits4 = f(4)
+            renderer.trace_primary_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, hits4, None, spp=spp, seed=seed, jitter=True, stream=s)
+            torch.cuda.synchronize()
+            got[path] = [t.clone() for t in (ra, hits, ra2, hits2, thr, rad, nxt, thr3, rad3, nxt3, hits4)]
+        names = ("rays", "hits", "rays (fused call)", "hits (fused call)", "throughput", "radiance", "next rays",
+                 "throughput (no copies)", "radiance (no copies)", "next rays (no copies)", "hits (no ray copy)")
+        for a, b, what in zip(got[1], got[2], names):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (world, rank, what)
+        assert torch.equal(got[2][0].view(torch.int32), got[2][2].view(torch.int32)) and torch.equal(got[2][1].view(torch.int32), got[2][10].view(torch.int32))
+    renderer.set_option(rt.OPT_PRIMARY, 0)
+    with pytest.raises(RuntimeError):
+        renderer.set_option(rt.OPT_PRIMARY, 3)
+
+
 def test_rt_render_matches_oracle_frame():
     """rt_render (host RGBA8, two replicas on the one GPU = the in-process multi-device path) against orc_render;
     the reference's own SAMPLES/BOUNCES are 10/8 (frag.glsl:3-4), here 4/5 on 96x72 to keep the oracle quick."""
