@@ -66,8 +66,9 @@ enum {
                                3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected. */
     RT_OPT_PRIMARY = 10     /* primary rays: 1 = tile kernel (8x8 pixels per wave, generation fused with traversal and, in
                                rt_primary_shade_stripes_dev, with the first shading segment); 2 = ray generation into a
-                               buffer + the ray-buffer kernel (+ the first-segment shade); 0 auto = 2 when nodes +
-                               triangles exceed 48 MB, else 1 (default).  Same rays, hits and path state either way. */
+                               buffer + the ray-buffer kernel (+ the first-segment shade); 0 auto = 2 when the tree's SAH
+                               cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for soup-like scenes whose neighbouring
+                               rays walk unrelated paths, else 1 (default).  Same rays, hits and path state either way. */
 };
 
 /* Scene / acceleration-structure statistics after rt_scene_upload. */

@@ -168,14 +168,18 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
                         perm ? bin_flag(perm, n) : nullptr, spill, c->lds_stack);
 }
 
-// Primary rays of a big tree go through the ray-buffer kernel (ray generation -> k_trace_strip): the tile kernel sizes
-// LDS for the tree's worst-case stack and walks each ray to the end (C5: 50 ms against 17 ms); on cache-resident
-// scenes the tile kernel is the faster one (C3: 2.7 against 3.7 ms).  Same rays, same hits either way.
+// Primary rays of a "hard" tree go through the ray-buffer kernel (ray generation -> k_trace_strip).  What decides is
+// not the size of the scene but how long and how divergent traversals are, which the tree's SAH cost predicts: on
+// random soups (SAH cost 300..1800) neighbouring pixels walk unrelated paths and the tile kernel, which walks each ray
+// of a wave to the end, loses (10 M triangles: 50 ms against 17 ms); on tessellated surfaces (SAH cost 8..72, up to
+// 8 M triangles measured) neighbouring rays stay together and the tile kernel is ahead (C3: 2.7 against 3.7 ms).
+// Crossover measured at SAH cost ~250 (scripts/primary_threshold*.py).  Same rays, same hits either way.
+constexpr float kPrimaryBufferSah = 250.0f;
 bool primary_via_buffer(const rt_ctx* c) {
     const int mode = c->mode();
     if (mode == kBrute || c->strip < 64 || c->counters || c->primary_path == 1) return false;
     if (c->primary_path == 2) return true;
-    return (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48 > kBinMinSceneBytes;
+    return c->stats.sah_cost > kPrimaryBufferSah;
 }
 
 // rays (32 B) and / or hits (16 B) for n local ray slots from the slot's scratch when the caller passes none

@@ -104,15 +104,16 @@ def bunny_class():
     return tris, np.zeros(0, dtype=SPHERE), lights, cam
 
 
-def sponza_class():
+def sponza_class(tess=45):
     """C3 stand-in ("sponza-class"): 8 x 8 grid of sphereGeometry(45,45) (4,050 triangles each = 259,200)
-    inside a closed 12-triangle room = 259,212 triangles; camera inside the room.  NOT Sponza."""
+    inside a closed 12-triangle room = 259,212 triangles; camera inside the room.  NOT Sponza.
+    `tess` other than 45 gives the same scene at another tessellation (scaling probes only)."""
     parts = [box((-8.5, -8.5, 0.0), (8.5, 8.5, 5.0))]
     for i in range(8):
         for j in range(8):
             z = 0.8 + 0.35 * ((i * 3 + j * 5) % 7)
             alb = (0.3 + 0.1 * (i % 5), 0.3 + 0.1 * (j % 5), 0.6)
-            parts.append(sphere_geometry((-7.0 + 2.0 * i, -7.0 + 2.0 * j, z), 0.8, 45, 45, material12(alb)))
+            parts.append(sphere_geometry((-7.0 + 2.0 * i, -7.0 + 2.0 * j, z), 0.8, tess, tess, material12(alb)))
     tris = cat(parts)
     cam = camera_look_at((0.3, 8.0, 2.6), (0.0, 0.0, 1.2), 60.0, 3840.0 / 2160.0)
     return tris, np.zeros(0, dtype=SPHERE), np.zeros(0, dtype=LIGHT), cam
