@@ -14,7 +14,7 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/reps
-r = rt.Renderer((0,)); r.set_option(rt.OPT_TRAVERSAL, 2)
+r = rt.Renderer((0,)); r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
 for leaf in (1, 2, 3, 4, 6, 8):
     r.set_option(rt.OPT_MAX_LEAF, leaf)
     st = r.create_data(tris, sph); r.update_camera(cam)
