@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
         if (node < 0 && node != kDone && pend == 0) { pend = node; --sp; node = CAPPED ? st_read(stk, spill, sp) : stk[sp * kBlock]; }
         const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);
-        if (__popcll(mt) >= tth || __ballot(node >= 0) == 0ull) {
+        if ((int)__popcll(mt) >= tth || __ballot(node >= 0) == 0ull) {
             if (COUNT) w_t += __popcll(mt);
             if (need_t) {
                 const uint32_t ref = ~(uint32_t)pend;              // (first << 3) | (remaining - 1)
