@@ -10,7 +10,7 @@ every stage on device, nothing skipped:
                     (frag.glsl:310-350)
   2. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent)
   3. k_shade_resolve  radiance of the second (last) segment + average, gamma -> RGBA8 framebuffer (frag.glsl:357-359)
-  4. N > 1 only: all-gather of the per-rank framebuffer stripes over RCCL/xGMI + de-interleave
+  4. N > 1 only: gather of the per-rank framebuffer stripes to rank 0 over RCCL/xGMI + de-interleave
 value = closest-hit rays of the whole job / wall time (max over ranks).  With N ranks the frame's 16-row
 stripes are interleaved over the ranks (BVH replicated): total work is fixed, so scaling is "strong".
 
@@ -118,12 +118,19 @@ def main():
         # radiance of the second (last) segment + resolve in one launch: the final radiance stays in registers
         r.shade_resolve_dev(brays, bhits, n_local, SPP, thr, rad, None, fb, stream=stream)
 
+    gather_all = os.environ.get("RT_BENCH_GATHER", "root") == "all"          # "all": every rank gets the frame (all-gather)
+
     def stage_gather():
+        # per-rank RGBA8 stripes -> the frame on rank 0 (what shows it): each rank sends its 4 MB once, over its own
+        # xGMI link to rank 0 (RCCL send/recv), and rank 0 de-interleaves the stripes with one index_select
         if world == 1:
             return fb
+        mine = fb.view(plan.padded_rows, W)
         if backend != "nccl":                                                    # rehearsal: stage through the host
-            return rd.gather_rows(fb.view(plan.padded_rows, W).cpu(), plan, gidx.cpu())
-        return rd.gather_rows(fb.view(plan.padded_rows, W), plan, gidx)          # [H, W] RGBA8 on every rank
+            mine, idx = mine.cpu(), gidx.cpu()
+        else:
+            idx = gidx
+        return rd.gather_rows(mine, plan, idx) if gather_all else rd.gather_rows_to(mine, plan, 0, idx)
 
     stages = [stage_primary_shade, stage_bounce_trace, stage_shade2_resolve, stage_gather]
 

@@ -6,8 +6,8 @@ cross-pixel communication), so the only exchange is the gather of per-rank resul
 
   * image configs: the frame is cut into horizontal stripes of `stripe_h` rows (a multiple of the 8x8
     wave tile); rank r owns stripes r, r+N, r+2N, ... (interleaved, because cost is spatially uneven);
-    the per-rank buffers are all-gathered (RCCL over xGMI when the backend is "nccl") and
-    de-interleaved into image order on every rank.
+    the per-rank buffers are gathered to one rank (gather_rows_to) or all-gathered (gather_rows) -- RCCL
+    over xGMI when the backend is "nccl" -- and de-interleaved into image order.
   * ray-buffer configs (C4): contiguous ranges of ceil(n/N) rays per rank, all-gathered the same way.
 
 No reduction is involved, so no all-reduce: each element has exactly one owner.
@@ -84,6 +84,29 @@ def gather_rows(local, plan, index=None, group=None):
         full = torch.empty((plan.world * plan.padded_rows,) + tuple(local.shape[1:]), dtype=local.dtype,
                            device=local.device)
         dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    if index is None:
+        index = gather_index(plan, local.device)
+    return full.index_select(0, index)
+
+
+def gather_rows_to(local, plan, dst=0, index=None, group=None):
+    """Like gather_rows, but only rank `dst` receives the frame ([h, row_elems...]; None elsewhere): every other rank
+    sends its stripes once, over its own direct xGMI link to dst, instead of the N-1 hops of a ring all-gather.
+    This is the exchange the reference's presentation needs -- one process shows the frame."""
+    if local.shape[0] != plan.padded_rows:
+        raise ValueError(f"local buffer has {local.shape[0]} rows, plan needs {plan.padded_rows}")
+    if plan.world == 1:
+        full = local
+    else:
+        local = local.contiguous()
+        full, parts = None, None
+        if plan.rank == dst:
+            full = torch.empty((plan.world * plan.padded_rows,) + tuple(local.shape[1:]), dtype=local.dtype,
+                               device=local.device)
+            parts = list(full.chunk(plan.world, dim=0))             # contiguous views: received in place
+        dist.gather(local, parts, dst=dst, group=group)
+        if plan.rank != dst:
+            return None
     if index is None:
         index = gather_index(plan, local.device)
     return full.index_select(0, index)

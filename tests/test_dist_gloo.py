@@ -69,6 +69,11 @@ def _worker(rank, world, port, h, w, sh, n):
         full = rd.gather_rows(local, p)
         want = (torch.arange(h * w, dtype=torch.float32).reshape(h, w, 1)) * torch.tensor([1.0, 2.0, 3.0, 4.0])
         assert torch.equal(full, want)
+        for dst in range(world):                       # gather to one rank: the frame on dst, None elsewhere
+            one = rd.gather_rows_to(local, p, dst=dst)
+            assert (one is None) == (rank != dst)
+            if rank == dst:
+                assert torch.equal(one, want)
         # ray ranges
         first, cnt, per = rd.shard_range(n, world, rank)
         loc = torch.zeros(per, 4)
