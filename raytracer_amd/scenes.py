@@ -6,6 +6,7 @@ labelled procedural stand-ins of SURVEY.md 8(d), built from the reference's own 
 (src/math/Sphere.h:17-79).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -90,9 +91,35 @@ def box(lo, hi, mat=None):
     return cat(q)
 
 
+def real_mesh(env_var, aspect, fov_deg=45.0):
+    """a real mesh (Bunny / Sponza / San Miguel) is used when `env_var` names a readable OBJ file --
+    none ships with the reference or this repository.  Returns (tris, camera framing the mesh's bounding box, light
+    above it) or None.  Every triangle gets the default grey material of rt_load_obj."""
+    path = os.environ.get(env_var, "")
+    if not path or not os.path.isfile(path):
+        return None
+    from . import load_obj
+    tris = load_obj(path)
+    if len(tris) == 0:
+        return None
+    p = np.concatenate([tris[v]["position"] for v in ("v0", "v1", "v2")])
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    ctr, ext = (lo + hi) / 2, float(np.max(hi - lo))
+    eye = ctr + np.array([0.35, -1.0, 0.45], dtype=np.float32) * ext * 1.6
+    cam = camera_look_at(tuple(float(x) for x in eye), tuple(float(x) for x in ctr), fov_deg, aspect)
+    lights = np.zeros(1, dtype=LIGHT)
+    lights[0]["position"] = tuple(float(x) for x in ctr + np.array([0.5, -0.5, 1.5], dtype=np.float32) * ext)
+    lights[0]["color"] = (1, 1, 1)
+    lights[0]["intensity"] = 5.0 * ext * ext
+    return tris, cam, lights
+
+
 def bunny_class():
     """C2 stand-in ("bunny-class"): sphereGeometry(186,186) = 69,192 triangles above a 2-triangle ground
     quad (so that the shadow ray has something to fall on); one point light.  NOT the Stanford Bunny."""
+    real = real_mesh("RT_BUNNY_OBJ", 1920.0 / 1080.0)
+    if real is not None:                                   # the real mesh, if the caller has one
+        return real[0], np.zeros(0, dtype=SPHERE), real[2], real[1]
     body = sphere_geometry((0.0, 0.0, 1.0), 1.0, 186, 186, material12((0.8, 0.8, 0.7)))
     ground = _quad((-6, -6, 0), (6, -6, 0), (6, 6, 0), (-6, 6, 0), (0, 0, 1), material12())
     tris = cat([body, ground])
@@ -108,6 +135,9 @@ def sponza_class(tess=45):
     """C3 stand-in ("sponza-class"): 8 x 8 grid of sphereGeometry(45,45) (4,050 triangles each = 259,200)
     inside a closed 12-triangle room = 259,212 triangles; camera inside the room.  NOT Sponza.
     `tess` other than 45 gives the same scene at another tessellation (scaling probes only)."""
+    real = real_mesh("RT_SPONZA_OBJ", 3840.0 / 2160.0, 60.0) if tess == 45 else None
+    if real is not None:                                   # the real mesh, if the caller has one
+        return real[0], np.zeros(0, dtype=SPHERE), np.zeros(0, dtype=LIGHT), real[1]
     parts = [box((-8.5, -8.5, 0.0), (8.5, 8.5, 5.0))]
     for i in range(8):
         for j in range(8):

@@ -94,3 +94,13 @@ def test_missing_file_and_empty_file(tmp_path):
     with pytest.raises(RuntimeError):
         rt.load_obj(str(tmp_path / "nope.obj"))
     assert len(rt.load_obj(write(tmp_path, "# nothing\n"))) == 0
+
+
+def test_real_mesh_hook_of_the_scene_setup(tmp_path, monkeypatch):
+    """C2/C3 use the procedural stand-ins unless RT_BUNNY_OBJ / RT_SPONZA_OBJ name a mesh."""
+    assert len(scenes.bunny_class()[0]) == 69194
+    monkeypatch.setenv("RT_BUNNY_OBJ", write(tmp_path, CUBE, "bunny.obj"))
+    tris, sph, lights, cam = scenes.bunny_class()
+    assert len(tris) == 6 and len(sph) == 0 and len(lights) == 1 and cam.dtype == rt.CAMERA
+    monkeypatch.setenv("RT_BUNNY_OBJ", str(tmp_path / "absent.obj"))
+    assert len(scenes.bunny_class()[0]) == 69194
