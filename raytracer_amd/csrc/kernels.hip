@@ -646,13 +646,24 @@ template <int MODE, bool COUNT, bool SHADE>
 __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
                                                     uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
                                                     uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
-                                                    float4* __restrict__ hits, unsigned long long* counters, ShadeOut so) {
+                                                    float4* __restrict__ hits, unsigned long long* counters, ShadeOut so, int quad) {
     extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t tile = wave / spp, smp = wave - tile * spp;
-    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const uint32_t x = tx * 8 + (lane & 7), yl = ty * 8 + (lane >> 3);
+    // lane -> (pixel, sample): an 8x8 pixel tile for one sample, or -- when spp is a multiple of 4 (tiles_x then counts
+    // 4-pixel columns, the launcher sets quad) -- a 4x4 pixel tile for four samples: the samples of one pixel are
+    // almost the same ray, so the wave stays together longer
+    uint32_t x, yl, smp;
+    if (quad) {
+        const uint32_t groups = spp >> 2, tile = wave / groups, sg = wave - tile * groups;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        x = tx * 4 + ((lane >> 2) & 3); yl = ty * 4 + (lane >> 4); smp = sg * 4 + (lane & 3);
+    } else {
+        const uint32_t tile = wave / spp;
+        smp = wave - tile * spp;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        x = tx * 8 + (lane & 7); yl = ty * 8 + (lane >> 3);
+    }
     // local row yl -> image row: stripes of stripe_h rows, every stripe_step-th stripe belongs to this launch
     const uint32_t y = y0 + (yl / stripe_h) * stripe_h * stripe_step + (yl % stripe_h);
     const bool active = wave < n_waves && x < w && yl < rows && y < h;
@@ -1061,8 +1072,9 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
     if (mode == kNone && (shade || count || !d_rays_out)) return hipErrorInvalidValue;      // kNone: ray generation only
     if (mode != kNone && !shade && !d_hits) return hipErrorInvalidValue;
     if (shade && (!shade->d_throughput || !shade->d_radiance)) return hipErrorInvalidValue;
-    const uint32_t tiles_x = (w + 7) / 8, tiles_y = (rows + 7) / 8;
-    const uint64_t n_waves64 = (uint64_t)tiles_x * tiles_y * spp;
+    const int quad = (spp % 4 == 0) ? 1 : 0;
+    const uint32_t tiles_x = quad ? (w + 3) / 4 : (w + 7) / 8, tiles_y = quad ? (rows + 3) / 4 : (rows + 7) / 8;
+    const uint64_t n_waves64 = (uint64_t)tiles_x * tiles_y * (quad ? spp / 4 : spp);
     if (n_waves64 > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t n_waves = (uint32_t)n_waves64;
     dim3 g((n_waves + kBlock / 64 - 1) / (kBlock / 64)), b(kBlock);
@@ -1071,9 +1083,9 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
     ShadeOut so = { nullptr, nullptr, nullptr, 0u };
     if (shade) so = ShadeOut{ shade->d_throughput, shade->d_radiance, reinterpret_cast<float4*>(shade->d_next), shade->seed };
 #define RT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_primary<M, C, S>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
-                                              jitter, tiles_x, n_waves, rays, hits, d_counters, so)
+                                              jitter, tiles_x, n_waves, rays, hits, d_counters, so, quad)
 #define RT_LAUNCH_M(M) do { if (shade) RT_LAUNCH(M, false, true); else if (count) RT_LAUNCH(M, true, false); else RT_LAUNCH(M, false, false); } while (0)
-    if (mode == kNone) hipLaunchKernelGGL((k_primary<kNone, false, false>), g, b, 0, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays, nullptr, d_counters, so);
+    if (mode == kNone) hipLaunchKernelGGL((k_primary<kNone, false, false>), g, b, 0, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays, nullptr, d_counters, so, quad);
     else if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_M
