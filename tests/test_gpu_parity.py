@@ -164,6 +164,26 @@ def test_jittered_spp_primary_rays_bit_exact(renderer, torch_dev):
     assert_parity(to_np(hits, rt.HIT), oracle.trace(oracle.Scene(tris, sph), ref_rays), "jittered primary hits")
 
 
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH])
+@pytest.mark.parametrize("w,h,spp", [(37, 21, 1), (37, 21, 2), (29, 13, 6), (21, 10, 10), (33, 9, 8), (19, 7, 5)])
+def test_sample_grouping_of_the_tile_kernel(renderer, torch_dev, mode, w, h, spp):
+    """A wave of the tile kernel takes 4, 2 or 1 samples of a 4x4, 8x4 or 8x8 pixel tile, whichever divides spp (the
+    reference's own SAMPLES is 10): every grouping must give the oracle's rays and hits in (pixel, sample) order, on
+    ragged image sizes too."""
+    torch = torch_dev
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(w / h)
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    renderer.create_data(tris, sph)
+    renderer.update_camera(cam)
+    rays, hits = dev_buf(torch, w * h * spp, 32), dev_buf(torch, w * h * spp, 16)
+    renderer.trace_primary_dev(w, h, hits, rays, spp=spp, seed=7, jitter=True, stream=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    ref_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=7, jitter=True)
+    assert to_np(rays, rt.RAY).tobytes() == ref_rays.tobytes()
+    assert_parity(to_np(hits, rt.HIT), oracle.trace(oracle.Scene(tris, sph), ref_rays), f"spp {spp}")
+
+
 # ---- edge cases -----------------------------------------------------------------------------------------
 def test_empty_scene_and_empty_ray_buffer(renderer):
     renderer.create_data()
