@@ -653,3 +653,15 @@ def test_rt_render_matches_oracle_frame():
         assert got.shape == (72, 96, 4) and (got[..., 3] == 255).all()
         assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1, devs
         assert got[..., :3].mean() > 20                                   # the emissive panel lights the box
+
+
+def test_adversarial_ties_and_epsilon_cases():
+    """scripts/fuzz_ties.py: coplanar grids with shared edges / vertices, duplicated triangles, slivers, zero-area triangles,
+    coincident spheres; rays aimed exactly at vertices and edge midpoints, in-plane and axis-parallel.  0 differing records
+    between every BVH mode / kernel and the brute-force kernel, and between that kernel and the CPU oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_ties.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 differing records (rate 0.00e+00)" in p.stdout
