@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 template <int MODE, bool ANY, bool COUNT, bool CAPPED>
 __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
-                                                        unsigned long long* __restrict__ work /* 8 chunk cursors, 0 at launch */,
+                                                        unsigned long long* __restrict__ work /* 8 chunk cursors + mask, kCursorStride apart, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
                                                         const uint32_t* __restrict__ perm_on /* device flag, null = on */,
                                                         int* __restrict__ spill_base /* CAPPED: [entry][thread of the launch] */, int lds_cap,
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     bool more = true;                                                 // wave-uniform: some cursor is not exhausted
     const uint64_t n_chunks = (n + strip - 1) / strip;
     const uint32_t per_q = (uint32_t)((n_chunks + 7) / 8);            // chunks per eighth
-    uint32_t q = blockIdx.x & 7u, q_tried = 0;                        // workgroups go round-robin over the 8 XCDs
+    uint32_t q = blockIdx.x & 7u, q_done = 0;                         // workgroups go round-robin over the 8 XCDs
     const Spill spill = { CAPPED ? spill_base + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr, (size_t)gridDim.x * kBlock, lds_cap };
     stk[0] = kDone;
     int node = kDone, sp = 1;
@@ -410,16 +410,29 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
             // contiguous -- with binning: spatially compact -- part of the rays), then the other eighths
             cursor = end = 0;
             while (more) {
-                unsigned long long c0 = 0;
-                if ((threadIdx.x & 63) == 0) c0 = atomicAdd(&work[q], 1ull);
-                const uint64_t ci = (uint64_t)q * per_q + __builtin_amdgcn_readfirstlane((uint32_t)c0);
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c0) < per_q && ci < n_chunks) {
-                    cursor = ci * strip;
+                const uint64_t first = (uint64_t)q * per_q;
+                const uint32_t left = first >= n_chunks ? 0u : (per_q < n_chunks - first ? per_q : (uint32_t)(n_chunks - first));
+                unsigned long long c0 = ~0ull;
+                if (left && (threadIdx.x & 63) == 0) c0 = atomicAdd(&work[q * kCursorStride], 1ull);
+                const uint32_t got = __builtin_amdgcn_readfirstlane((uint32_t)c0);
+                if (got < left) {
+                    cursor = (first + got) * strip;
                     end = (cursor + strip < n) ? cursor + strip : n;
                     break;
                 }
-                q = (q + 1u) & 7u;
-                if (++q_tried == 8u) more = false;
+                // This eighth is exhausted.  Thousands of waves get here at the end of a launch; failed draws on the
+                // other cursors would serialise in the L2 (0.75 ms per launch, measured), so exhausted eighths are
+                // published once in a mask word on its own line and later waves skip them after one plain load.
+                uint32_t mask = 0;
+                if ((threadIdx.x & 63) == 0) {
+                    mask = (uint32_t)__hip_atomic_load(&work[8 * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(mask & (1u << q))) atomicOr(&work[8 * kCursorStride], 1ull << q);
+                }
+                q_done |= __builtin_amdgcn_readfirstlane(mask) | (1u << q);
+                const uint32_t cand = ~q_done & 0xffu;
+                if (cand == 0u) { more = false; break; }
+                const uint32_t rot = ((cand >> q) | (cand << (8u - q))) & 0xffu;        // next open eighth after q, cyclic
+                q = (q + (uint32_t)__builtin_ctz(rot)) & 7u;
             }
         }
         if (cursor < end && n_idle >= refill) {
@@ -1029,14 +1042,23 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         // strip kernel: persistent waves, as many blocks as the chip holds at once (LDS-limited), never more than
         // there are chunks.  The chunk cursor is one slot of a ring behind the counters, zeroed on the stream.
         static std::atomic<uint32_t> seq{0};
-        unsigned long long* work = d_counters + kNumCounters + (size_t)(seq.fetch_add(1) % kWorkSlots) * 8;
-        hipError_t e = hipMemsetAsync(work, 0, 8 * sizeof(unsigned long long), st);
+        unsigned long long* work = d_counters + kCountersPad + (size_t)(seq.fetch_add(1) % kWorkSlots) * kWorkWords;
+        hipError_t e = hipMemsetAsync(work, 0, kWorkWords * sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;
+        // chunk size: the option is the maximum; smaller buffers get smaller chunks (down to one wave's worth), so that
+        // a full grid still draws >= 8 chunks per wave and the launch does not end in a long tail of half-empty waves
+        {
+            const uint64_t want = n / (8ull * 8ull * (uint64_t)num_cus() * (kBlock / 64));     // rays per chunk for 8 chunks per wave
+            uint32_t fit = 64;
+            while ((uint64_t)fit * 2 <= want && fit * 2 <= strip) fit *= 2;
+            strip = fit;
+        }
         const bool capped = mode == kBvh4q && d_spill && lds_cap >= 2 && s.stack_depth + 2 > (uint32_t)lds_cap;
         const size_t lds = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
         const uint64_t n_chunks = (n + strip - 1) / strip;
-        const uint64_t blocks = std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus());
+        // never more waves than an eighth of the chunks: a wave that gets only a chunk or two is all start-up and tail
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 8 * (kBlock / 64) - 1) / (8 * (kBlock / 64)), per_cu * (uint64_t)num_cus()));
         dim3 g((uint32_t)blocks);
 #define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M, P) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P); else RT_LAUNCH(M, true, false, P); } \

@@ -91,6 +91,9 @@ hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w
 
 constexpr int kStackDepth = 32;   // BVH2 depth budget + 2: bounds the per-lane traversal stack of the BVH2 layout
 constexpr int kWorkSlots = 64;    // ring of chunk-cursor sets (8 cursors each) of the strip kernel, stored behind the counters (one set per launch in flight)
+constexpr int kCursorStride = 16;       // u64 words between chunk cursors: one 128-B line each, so they sit in different L2 channels
+constexpr int kWorkWords = 9 * kCursorStride;   // 8 cursors + the mask of exhausted eighths
+constexpr int kCountersPad = 16;        // the counters take the first line of the buffer, the cursor sets follow
 constexpr int kNumCounters = 8;   // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves
 
 }  // namespace rt

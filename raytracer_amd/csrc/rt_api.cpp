@@ -248,8 +248,8 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
         Replica& r = c->reps[i];
         r.device = d;
         if (hipSetDevice(d) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipMalloc(&r.d_counters, (kNumCounters + kWorkSlots * 8) * sizeof(unsigned long long)) != hipSuccess ||
-            hipMemset(r.d_counters, 0, (kNumCounters + kWorkSlots * 8) * sizeof(unsigned long long)) != hipSuccess) {
+            hipMalloc(&r.d_counters, (kCountersPad + (size_t)kWorkSlots * kWorkWords) * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(r.d_counters, 0, (kCountersPad + (size_t)kWorkSlots * kWorkWords) * sizeof(unsigned long long)) != hipSuccess) {
             rt_destroy(c);
             return RT_E_DEVICE;
         }
