@@ -10,7 +10,7 @@ W, H, SPP = 3840, 2160, 4; n = W * H * SPP
 f = lambda k: torch.empty(n * k, dtype=torch.float32, device='cuda')
 rays, hits, brays, bhits = f(8), f(4), f(8), f(4)
 r.trace_primary_dev(W, H, hits, rays, spp=SPP, seed=1, jitter=True); r.bounce_dev(rays, hits, n, brays, seed=1)
-for strip, tth, refill, binning, cap in ((256, 24, 16, 0, 20), (256, 32, 16, 0, 20), (256, 16, 16, 0, 20), (256, 24, 24, 0, 20), (256, 40, 16, 0, 20)):
+for strip, tth, refill, binning, cap in ((256, 24, 16, 0, 20), (256, 16, 16, 0, 20), (256, 32, 16, 0, 20), (256, 24, 8, 0, 20), (256, 24, 24, 0, 20), (128, 24, 16, 0, 20), (512, 24, 16, 0, 20), (256, 24, 16, 0, 16), (256, 24, 16, 0, 24)):
     r.set_option(rt.OPT_STRIP, strip); r.set_option(rt.OPT_REFILL, refill | (tth << 8)); r.set_option(rt.OPT_RAY_BINNING, binning); r.set_option(rt.OPT_LDS_STACK, cap)
     r.trace_dev(brays, n, bhits); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
