@@ -1057,8 +1057,9 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         const size_t lds = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
         const uint64_t n_chunks = (n + strip - 1) / strip;
-        // never more waves than an eighth of the chunks: a wave that gets only a chunk or two is all start-up and tail
-        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 8 * (kBlock / 64) - 1) / (8 * (kBlock / 64)), per_cu * (uint64_t)num_cus()));
+        // a full grid when there are chunks for it (>= 8 per wave by the chunk size above, down to 1 for small buffers,
+        // where putting every ray in flight at once matters more than the tail)
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));
         dim3 g((uint32_t)blocks);
 #define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M, P) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P); else RT_LAUNCH(M, true, false, P); } \
