@@ -14,20 +14,58 @@ every stage on device, nothing skipped:
 value = closest-hit rays of the whole job / wall time (max over ranks).  With N ranks the frame's 16-row
 stripes are interleaved over the ranks (BVH replicated): total work is fixed, so scaling is "strong".
 
-Usage: python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run.
+Usage: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either launch it with torch.distributed.run (one rank
+per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or run it plainly: without WORLD_SIZE in the
+environment it starts the N ranks itself, as a torch.distributed.run child process, before anything touches the GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal", type=int, default=3, help="2 = BVH2 nodes, 3 = BVH4q nodes")
+    return ap.parse_args(argv)
+
+
+def launcher_command(args, argv, port):
+    """The torch.distributed.run command line that starts `args.gpus` ranks of this script on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(args, env):
+    return args.gpus > 1 and "WORLD_SIZE" not in env
+
+
+def self_launch(args, argv):
+    """N > 1 without a launcher: become the launcher.  Runs before torch.cuda / HIP is touched in this process (the
+    ranks are children; nothing here initialises the GPU), prints what rank 0 prints, returns the child's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(launcher_command(args, argv, port), env=env)
+
+
+if __name__ == "__main__" and needs_self_launch(parse_args(), os.environ):
+    sys.exit(self_launch(parse_args(), sys.argv[1:]))
+
+import numpy as np                              # noqa: E402
+import torch                                    # noqa: E402
+import torch.distributed as dist                # noqa: E402
 
 import raytracer_amd as rt                      # noqa: E402
 from raytracer_amd import dist as rd            # noqa: E402
@@ -41,6 +79,7 @@ PEAK_VALU_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 CPU_SAMPLE = 65536            # rays per generation in the CPU-baseline / parity sample
 CPU_BVH_SAMPLE = 1 << 24      # rays per generation for the CPU BVH walk (fair CPU row + wide parity gate)
+XFER_SAMPLE = 1 << 24         # rays of the transfer-inclusive figure (512 MB in, 256 MB out)
 
 
 def flops_bytes_per_ray(c, generated):
@@ -53,20 +92,12 @@ def flops_bytes_per_ray(c, generated):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traversal", type=int, default=rt.TRAVERSAL_BVH, help="2 = BVH2 nodes, 3 = BVH4q nodes")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:                       # launched by torch.distributed.run: the launcher's world size rules
         args.gpus = world
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")             # "gloo": rehearsal of N ranks on ONE GPU
     if backend == "gloo":
@@ -232,6 +263,9 @@ def main():
                            "depth": stats["max_depth"], "node_bytes": stats["node_bytes"],
                            "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
         "frame_sha256": frame_sha,       # RGBA8 framebuffer: identical for every N (decomposition-invariant RNG keys)
+        "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
+                  "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
+                  "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0")},
         "roofline": roofline, "roofline_hbm": roofline_hbm,
         "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_shade_ms": round(ms_primary, 4),
                     "primary_work_per_ray": w_p, "primary_tflops": round(fl_p * n_real_local / (ms_primary * 1e-3) / 1e12, 3),
@@ -283,6 +317,43 @@ def main():
         out["parity"].update({"bvh_walk_sample_rays": 2 * m,
                               "bvh_walk_prim_id_mismatches": int((w_hits["prim"] != g_hits["prim"]).sum() + (w_bhits["prim"] != g_bhits["prim"]).sum()),
                               "bvh_walk_bit_exact": bool(w_hits.tobytes() == g_hits.tobytes() and w_bhits.tobytes() == g_bhits.tobytes())})
+    # ---- SURVEY 8(d) second figure: closest hit INCLUDING the transfers (host rays in, host hits out) ----------------
+    # What the reference's frame loop would call with host arrays (rt_trace): 2 Mi-ray pieces, H2D | kernel | D2H
+    # overlapped on two streams.  Never `value`.  The PCIe bound is 32 B in + 16 B out per ray over the measured link rates.
+    if world == 1:
+        m = min(n_local, XFER_SAMPLE)
+        h_rays = brays.view(-1, 8)[:m].cpu().numpy().view(rt.RAY).ravel()
+        want = bhits.view(-1, 4)[:m].cpu().numpy().view(rt.HIT).ravel()
+        p_rays, p_hits = r.host_alloc(m, rt.RAY), r.host_alloc(m, rt.HIT)
+        p_rays[:] = h_rays
+        pin_t = torch.from_numpy(p_rays.view(np.float32))              # pinned by rt_host_alloc
+        d_t = torch.empty(m * 8, dtype=torch.float32, device=dev)
+
+        def gbs(fn, nbytes, reps=3):
+            fn(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return nbytes * reps / (time.perf_counter() - t) / 1e9
+        h2d = gbs(lambda: d_t.copy_(pin_t, non_blocking=True), m * 32)
+        d2h = gbs(lambda: pin_t.copy_(d_t, non_blocking=True), m * 32)
+        p_rays[:] = h_rays
+        res = {}
+        for name, src, dst in (("pinned", p_rays, p_hits), ("pageable", h_rays, np.empty(m, dtype=rt.HIT))):
+            r.trace(src, out=dst)                                      # warm: staging buffers, scratch
+            t = time.perf_counter()
+            r.trace(src, out=dst)
+            dt = time.perf_counter() - t
+            res[name + "_Mrays_s"] = round(m / dt / 1e6, 1)
+            res[name + "_bit_exact"] = bool(dst.tobytes() == want.tobytes())
+        bound = 1.0 / (32.0 / (h2d * 1e9) + 0.0) / 1e6                 # full duplex: the 32 B/ray inbound leg is the longer one
+        res.update({"rays": int(m), "h2d_GBs": round(h2d, 1), "d2h_GBs": round(d2h, 1), "pcie_bound_Mrays_s": round(bound, 1),
+                    "pinned_frac_of_pcie_bound": round(res["pinned_Mrays_s"] / bound, 3),
+                    "note": "rt_trace on the bounce rays of the frame: host rays in (32 B), host hits out (16 B); pinned = blocks of "
+                            "rt_host_alloc, pageable = ordinary memory staged through pinned buffers by host threads"})
+        out["with_transfers"] = res
+        r.host_free(p_rays); r.host_free(p_hits)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -7,7 +7,8 @@
  * below names the reference seam it replaces (paths relative to /root/reference).
  *
  * Conventions (mirroring the reference: single caller thread, blocking calls, owner keeps its arrays):
- *   - return 0 on success, a negative RT_E_* code on failure; nothing is thrown across the ABI.
+ *   - return 0 on success, a negative RT_E_* code on failure; nothing is thrown across the ABI (every entry point
+ *     catches: std::bad_alloc and thread-creation failures become RT_E_NOMEM, anything else RT_E_INVALID).
  *     raytracer_amd/host/raytracer.hpp converts non-zero into std::runtime_error(rt_last_error()),
  *     the reference's own convention (src/main.cpp:8-14).
  *   - one caller thread per rt_ctx.  host_* buffers stay owned by the caller.
@@ -42,7 +43,7 @@ enum {
     RT_E_DEVICE = -2,       /* HIP runtime error; text in rt_last_error */
     RT_E_NO_SCENE = -3,     /* trace before rt_scene_upload */
     RT_E_NO_CAMERA = -4,    /* primary rays before rt_set_camera */
-    RT_E_NOMEM = -5,
+    RT_E_NOMEM = -5,        /* host allocation (or thread creation) failed; the context stays usable */
     RT_E_TOO_LARGE = -6
 };
 
@@ -52,7 +53,9 @@ enum {
                                (the node layout is chosen at rt_scene_upload: set this first) */
     RT_OPT_BVH_THREADS = 2, /* host threads for the BVH build; 0 = hardware concurrency capped at 16 */
     RT_OPT_COUNTERS = 3,    /* 1: *_dev closest-hit launches run the instrumented kernel and accumulate rt_counters */
-    RT_OPT_PAD_LOG2 = 4,    /* BVH boxes are padded by max|coordinate| * 2^-value (default 15); takes effect at upload */
+    RT_OPT_PAD_LOG2 = 4,    /* BVH boxes are padded by max|vertex coordinate| * 2^-value at upload, and every ray widens them by
+                               max|origin coordinate| * 2^-value on its own (default 15, range 4..20: below 2^-20 the
+                               conservative-traversal argument of DESIGN.md does not hold) */
     RT_OPT_MAX_LEAF = 5,    /* triangles per BVH leaf, 1..8 (default 4); takes effect at upload */
     RT_OPT_STRIP = 6,       /* ray-buffer kernel: rays per chunk a persistent wave draws (default 256); 0 = one ray per lane, no refill */
     RT_OPT_REFILL = 7,      /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 16),
@@ -64,11 +67,14 @@ enum {
     RT_OPT_LDS_STACK = 9,   /* ray-buffer kernel, BVH4q nodes: traversal-stack entries per lane kept in LDS (default 20, 2..64);
                                deeper entries spill to a per-slot area in HBM, which lets 8 waves per SIMD run instead of
                                3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected. */
-    RT_OPT_PRIMARY = 10     /* primary rays: 1 = tile kernel (8x8 pixels per wave, generation fused with traversal and, in
+    RT_OPT_PRIMARY = 10,    /* primary rays: 1 = tile kernel (8x8 pixels per wave, generation fused with traversal and, in
                                rt_primary_shade_stripes_dev, with the first shading segment); 2 = ray generation into a
                                buffer + the ray-buffer kernel (+ the first-segment shade); 0 auto = 2 when the tree's SAH
                                cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for soup-like scenes whose neighbouring
                                rays walk unrelated paths, else 1 (default).  Same rays, hits and path state either way. */
+    RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for
+                               measuring what it protects against only: rays that start hundreds of scene extents away
+                               then lose hits the reference loop finds (tests/test_gpu_parity.py, far-origin test). */
 };
 
 /* Scene / acceleration-structure statistics after rt_scene_upload. */
@@ -131,6 +137,13 @@ int  rt_bvh_build_host(const void* tris, uint32_t n_tris, uint32_t tri_stride, i
  * Replaces VkRenderer::updateUniformBuffer (src/vulkan/VkRenderer.cpp:855-862): 112-byte
  * Camera::UniformBufferObject (src/application/Camera.h:6-18). */
 int  rt_set_camera(rt_ctx* ctx, const void* camera_ubo112);
+
+/* Optional: pinned (page-locked) host memory for the arrays a renderer keeps for its lifetime -- rays in, hits out --
+ * the way VkRenderer keeps its host-visible buffers mapped (src/vulkan/VkRenderer.cpp:260-326).  The host-pointer entry
+ * points below DMA from / to such blocks directly; ordinary (pageable) memory is staged through pinned buffers by a few
+ * host threads instead (slower, same bits).  Blocks live until rt_host_free or rt_destroy. */
+int  rt_host_alloc(rt_ctx* ctx, size_t bytes, void** out);
+int  rt_host_free(rt_ctx* ctx, void* block);
 
 /* ---- launch (per frame) ------------------------------------------------------------------------
  * Replace the vkCmdDrawIndexed that runs frag.glsl:main once per pixel
@@ -224,7 +237,8 @@ int  rt_sync(rt_ctx* ctx, int slot);
 uint32_t rt_gen_cornell_triangles(void* tris144, uint32_t cap);               /* 12, VkRenderer.cpp:171-238 */
 uint32_t rt_gen_cornell_spheres(void* spheres64, uint32_t cap);               /* 3,  VkRenderer.cpp:240-250 */
 uint32_t rt_gen_sphere_geometry(const float center[3], float radius, uint32_t stacks, uint32_t slices,
-                                const float material12[12], void* tris144, uint32_t cap); /* Sphere.h:17-79 */
+                                const float material12[12], void* tris144, uint32_t cap); /* Sphere.h:17-79; 0 = count
+                                                                    exceeds 2^32-1 or out of host memory */
 uint32_t rt_gen_soup(uint64_t seed, uint32_t n, float half_extent, void* tris144, uint32_t cap); /* SURVEY C4 */
 void     rt_gen_random_rays(uint64_t seed, uint64_t first, uint64_t n, rt_ray* out);              /* SURVEY C4 */
 /* Default camera of VkRenderer::VkRenderer (src/vulkan/VkRenderer.cpp:3-12) with the basis of

@@ -38,7 +38,7 @@ RAY = np.dtype([("o", "3f4"), ("tmin", "f4"), ("d", "3f4"), ("tmax", "f4")])
 HIT = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("prim", "u4")])
 assert RAY.itemsize == 32 and HIT.itemsize == 16
 
-OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING, OPT_LDS_STACK, OPT_PRIMARY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING, OPT_LDS_STACK, OPT_PRIMARY, OPT_RAY_PAD = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
 TRAVERSAL_BVH = TRAVERSAL_BVH4Q
 
@@ -188,17 +188,32 @@ class Renderer:
             raise RuntimeError("camera UBO must be 112 bytes")
         self._check(self._lib.rt_set_camera(self._ctx, _ptr(ubo)))
 
+    def host_alloc(self, n, dtype):
+        """rt_host_alloc: a pinned numpy array of n records; trace / occluded DMA from / to it without staging copies.
+        Valid until host_free(array) or close()."""
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        self._check(self._lib.rt_host_alloc(self._ctx, max(n * dt.itemsize, 1), C.byref(p)))
+        buf = (C.c_char * (n * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=n)
+
+    def host_free(self, array):
+        self._check(self._lib.rt_host_free(self._ctx, _ptr(array)))
+
     # -- the draw (src/vulkan/VkRenderer.cpp:1123), host buffers ------------------------------------
     def trace_primary(self, w, h):
         out = np.empty(w * h, dtype=HIT)
         self._check(self._lib.rt_trace_primary(self._ctx, w, h, _ptr(out)))
         return out.reshape(h, w)
 
-    def trace(self, rays):
+    def trace(self, rays, out=None):
         rays = np.ascontiguousarray(rays)
         if rays.dtype != RAY:
             raise RuntimeError("rays must have dtype RAY (32 B)")
-        out = np.empty(len(rays), dtype=HIT)
+        if out is None:
+            out = np.empty(len(rays), dtype=HIT)
+        elif out.dtype != HIT or len(out) != len(rays) or not out.flags.c_contiguous:
+            raise RuntimeError("out must be a contiguous HIT array as long as rays")
         self._check(self._lib.rt_trace(self._ctx, _ptr(rays) if len(rays) else None, len(rays),
                                        _ptr(out) if len(rays) else None))
         return out

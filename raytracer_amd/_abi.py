@@ -38,6 +38,8 @@ SYMBOLS = [
     ("rt_scene_stats_get", _I, [_P, C.POINTER(rt_scene_stats)]),
     ("rt_bvh_build_host", _I, [_P, _U32, _U32, _I, _I, _I, _I, C.POINTER(rt_scene_stats), _P, _U64, _P]),
     ("rt_set_camera", _I, [_P, _P]),
+    ("rt_host_alloc", _I, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("rt_host_free", _I, [_P, _P]),
     ("rt_trace_primary", _I, [_P, _U32, _U32, _P]),
     ("rt_trace", _I, [_P, _P, _U64, _P]),
     ("rt_occluded", _I, [_P, _P, _U64, _P]),

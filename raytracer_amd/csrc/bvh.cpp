@@ -8,6 +8,8 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <exception>
+#include <system_error>
 #include <mutex>
 #include <thread>
 
@@ -31,6 +33,7 @@ struct Builder {
     std::deque<Task> queue;
     int pending = 0;          // tasks queued or running
     bool parallel = false;
+    std::exception_ptr failure;   // first exception of a worker (queue growth can throw); rethrown by build_bvh2
 
     static int ceil_log2(uint32_t x) { int l = 0; uint32_t v = 1; while (v < x) { v <<= 1; ++l; } return l; }
 
@@ -51,7 +54,13 @@ struct Builder {
                 t = queue.front();
                 queue.pop_front();
             }
-            build(t.node, t.begin, t.end, t.depth);
+            // nothing may escape a std::thread: keep the first exception, drain the queue without building
+            bool skip;
+            { std::lock_guard<std::mutex> g(mu); skip = (bool)failure; }
+            if (!skip) {
+                try { build(t.node, t.begin, t.end, t.depth); }
+                catch (...) { std::lock_guard<std::mutex> g(mu); if (!failure) failure = std::current_exception(); }
+            }
             {
                 std::lock_guard<std::mutex> g(mu);
                 if (--pending == 0) cv.notify_all();
@@ -181,9 +190,13 @@ void build_bvh2(const Aabb* prim_boxes, uint32_t n, const BuildParams& p, BuildR
         b.build(0, 0, n, 0);
     } else {
         b.spawn(Task{ 0, 0, n, 0 });
+        // nt - 1 helpers + this thread; a helper that cannot be started is simply missing
         std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t) pool.emplace_back([&b] { b.worker(); });
+        pool.reserve(nt);
+        try { for (int t = 1; t < nt; ++t) pool.emplace_back([&b] { b.worker(); }); } catch (...) {}      // std::system_error or std::bad_alloc
+        b.worker();
         for (auto& t : pool) t.join();
+        if (b.failure) std::rethrow_exception(b.failure);
     }
     out.nodes.resize(b.n_nodes.load());
 
@@ -336,6 +349,7 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
         Wide w{}; w.src = 0; w.n = 1; w.child[0] = 0;
         wide.push_back(w);
         out.depth = 1;
+        out.stack_need = 3;
     } else {
         st.push_back({ 0u, 1u, 0u });
         while (!st.empty()) {
@@ -345,10 +359,13 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
             ref[it.src] = (int32_t)wide.size();
             wide.push_back(w);
             out.depth = std::max(out.depth, it.depth);
-            // a visit may push up to n-1 siblings before descending
-            out.stack_need = std::max(out.stack_need, it.stack + (uint32_t)(w.n - 1));
+            // A visit may push up to THREE slots before descending, whatever the node's child count: the per-ray pad
+            // of the kernels (kernels.hip make_slab) can exceed a small node's whole extent for a ray that starts very far
+            // away, and then even its empty (inverted) slots pass the slab test and are pushed (they refer to triangle
+            // 0, which is harmless to test).  The bound must cover that, or such a ray overruns its stack.
+            out.stack_need = std::max(out.stack_need, it.stack + 3u);
             for (int k = w.n - 1; k >= 0; --k) {
-                if (b.nodes[w.child[k]].count == 0) st.push_back({ w.child[k], it.depth + 1, it.stack + (uint32_t)(w.n - 1) });
+                if (b.nodes[w.child[k]].count == 0) st.push_back({ w.child[k], it.depth + 1, it.stack + 3u });
             }
             // leaves are emitted when the wide node is written (below) to keep triangles of one node adjacent
         }

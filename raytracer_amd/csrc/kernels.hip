@@ -126,15 +126,27 @@ __device__ __forceinline__ float safe_rcp(float d) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Per-ray slab constants, duplicated into register pairs so that the (lo, hi) planes of one axis go through
-// one v_pk_fma_f32: t = plane * idir + (-o * idir).
+// Per-ray slab constants in register pairs, so that the two planes of one axis go through one v_pk_fma_f32:
+// t = plane * idir + (-o * idir).
+//
+// Per-ray pad.  The boxes are padded at build time by 2^-pad_log2 * max|vertex coordinate|, which covers rounding that
+// grows with the SCENE's magnitudes.  The slab arithmetic above and Moeller-Trumbore's s = o - v0 also work on numbers
+// of the ORIGIN's magnitude: the slab t is off by up to ~|o * idir| * 2^-23 (the two large terms cancel), and the
+// triangle test accepts rays that pass ~|o| * 2^-22 beside a triangle.  A ray that starts hundreds of scene extents away
+// would therefore lose leaves whose triangle the reference loop accepts.  So every ray widens every box by
+// m = ray_pad * max|o_a| (ray_pad = the same 2^-pad_log2) on its own: the entry t moves down and the exit t up by
+// m * |idir_a|, folded into the additive constants here -- the node step itself costs nothing more.
+// BVH4q pairs are (entry, exit); BVH2 pairs are (lo plane, hi plane), which move by -m / +m in space.
 struct Slab { v2f ix, iy, iz, ox, oy, oz; };
-__device__ __forceinline__ Slab make_slab(f3 o, f3 d) {
+template <int MODE>
+__device__ __forceinline__ Slab make_slab(f3 o, f3 d, float ray_pad) {
     const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const f3 od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
+    const float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) * ray_pad;
+    const f3 w = MODE == kBvh4q ? mk(m * fabsf(id.x), m * fabsf(id.y), m * fabsf(id.z)) : mk(m * id.x, m * id.y, m * id.z);
     Slab s;
     s.ix = (v2f){ id.x, id.x }; s.iy = (v2f){ id.y, id.y }; s.iz = (v2f){ id.z, id.z };
-    s.ox = (v2f){ od.x, od.x }; s.oy = (v2f){ od.y, od.y }; s.oz = (v2f){ od.z, od.z };
+    s.ox = (v2f){ od.x - w.x, od.x + w.x }; s.oy = (v2f){ od.y - w.y, od.y + w.y }; s.oz = (v2f){ od.z - w.z, od.z + w.z };
     return s;
 }
 
@@ -206,11 +218,12 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     const float sx = __uint_as_float((w << 23) & 0x7f800000u) * idx;
     const float sy = __uint_as_float((w << 15) & 0x7f800000u) * idy;
     const float sz = __uint_as_float((w << 7) & 0x7f800000u) * idz;
-    const float ax = __fmaf_rn(__uint_as_float(q0.x), idx, sl.ox.x);
-    const float ay = __fmaf_rn(__uint_as_float(q0.y), idy, sl.oy.x);
-    const float az = __fmaf_rn(__uint_as_float(q0.z), idz, sl.oz.x);
+    const float gx = __uint_as_float(q0.x), gy = __uint_as_float(q0.y), gz = __uint_as_float(q0.z);
     const v2f sx2 = (v2f){ sx, sx }, sy2 = (v2f){ sy, sy }, sz2 = (v2f){ sz, sz };
-    const v2f ax2 = (v2f){ ax, ax }, ay2 = (v2f){ ay, ay }, az2 = (v2f){ az, az };
+    // (entry, exit) constants of the node: grid origin * idir + the ray's (-o * idir -/+ per-ray pad)
+    const v2f ax2 = __builtin_elementwise_fma((v2f){ gx, gx }, sl.ix, sl.ox);
+    const v2f ay2 = __builtin_elementwise_fma((v2f){ gy, gy }, sl.iy, sl.oy);
+    const v2f az2 = __builtin_elementwise_fma((v2f){ gz, gz }, sl.iz, sl.oz);
     // The ray's direction signs pick, once per node and for all four children, which plane word is the entry
     // side and which the exit side: no per-axis min/max later.  Empty slots are stored inverted (lo 255, hi 0),
     // so their entry lies behind their exit whatever the signs and they miss without a count check.
@@ -282,7 +295,7 @@ __device__ __forceinline__ void trace_bvh(const DevScene& s, f3 o, f3 d, float t
     if (s.n_nodes == 0) return;
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
-    const Slab sl = make_slab(o, d);
+    const Slab sl = make_slab<MODE>(o, d, s.ray_pad);
     const float tmin0 = fmaxf(tmin, 0.0f);      // accepted hits have t > 1e-6 (frag.glsl:151) and t > 0 (:174)
     stk[0] = kDone;
     int sp = 1;
@@ -350,17 +363,19 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
     extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < n;
+    bool live = false;                                      // counters.rays = LIVE rays (tmax > tmin)
     Counters c = { 0, 0, 0, 0 };
     if (active) {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
         float4 r0 = rp[0], r1 = rp[1];
+        live = r1.w > r0.w;
         Best b;
         trace_ray<MODE, ANY, COUNT>(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w, b, c,
                                     stack + (MODE != kBrute ? threadIdx.x : 0));
         if (ANY) occ[i] = found(b, r1.w) ? 1 : 0;
         else     hits[i] = pack_hit(b, r1.w);
     }
-    flush_counters<COUNT>(c, active, counters);
+    flush_counters<COUNT>(c, live, counters);
 }
 
 // Ray-buffer closest-hit / any-hit with in-wave refill ("strip" kernel).  Incoherent rays finish at very
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
     int node = kDone, sp = 1;
     uint64_t my = 0;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
-    Slab sl = make_slab(o, d);
+    Slab sl = make_slab<MODE>(o, d, s.ray_pad);
     float tmin = 0.0f, tmin0 = 0.0f, tmax = 0.0f;
     Best b = { 0.0f, 0.0f, 0.0f, 0u };
     Counters c = { 0, 0, 0, 0 };
@@ -445,14 +460,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray
                 o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
                 tmin0 = fmaxf(tmin, 0.0f);
                 b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
-                if (COUNT) ++n_mine;
                 bool go = tmax > tmin;
+                if (COUNT && go) ++n_mine;                  // counters.rays = LIVE rays (dead slots are handed out too)
                 if (go) {
                     spheres_pass<COUNT>(s, o, d, tmin, b, c);
                     go = !(ANY && b.t < tmax) && s.n_nodes != 0;
                 }
                 if (go) {
-                    sl = make_slab(o, d);
+                    sl = make_slab<MODE>(o, d, s.ray_pad);
                     node = 0; sp = 1;
                 } else {
                     if (ANY) occ[my] = b.t < tmax ? 1 : 0;
@@ -1013,14 +1028,15 @@ inline int num_cus() {                        // of the current device (cached p
 
 int device_cus() { return num_cus(); }
 
-hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st) {
+hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st,
+                      uint32_t max_blocks) {
     if (n == 0) return hipSuccess;
-    if (n >= (1ull << 32)) return hipErrorInvalidValue;
+    if (n >= (1ull << 32) || max_blocks == 0) return hipErrorInvalidValue;
     uint32_t* perm = d_scratch;
     uint32_t* hist = d_scratch + n;
-    uint32_t* totals = hist + (size_t)kBinBlocksMax * kBins;
+    uint32_t* totals = hist + (size_t)max_blocks * kBins;
     uint32_t* meta = totals + kBins;                 // [0] permute flag, [1] non-empty (block, bin) pairs
-    const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(kBinBlocksMax, (n + 4095) / 4096);
+    const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(max_blocks, (n + 4095) / 4096);
     const uint64_t per_block = (n + n_blocks - 1) / n_blocks;
     hipError_t e = hipMemsetAsync(meta, 0, 4 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
@@ -1033,16 +1049,16 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
 
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
-                        uint32_t strip, int refill, const uint32_t* d_perm, const uint32_t* d_perm_on, int* d_spill, int lds_cap) {
+                        uint32_t strip, int refill, const uint32_t* d_perm, const uint32_t* d_perm_on, const StripScratch& sc) {
     if (n == 0) return hipSuccess;
     dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
     const int rf = refill & 0xff, tth = refill >> 8;
     if (mode != kBrute && strip >= 64) {
         // strip kernel: persistent waves, as many blocks as the chip holds at once (LDS-limited), never more than
-        // there are chunks.  The chunk cursor is one slot of a ring behind the counters, zeroed on the stream.
-        static std::atomic<uint32_t> seq{0};
-        unsigned long long* work = d_counters + kCountersPad + (size_t)(seq.fetch_add(1) % kWorkSlots) * kWorkWords;
+        // there are chunks.  The chunk cursors live in the caller's scratch (sc.work), zeroed on the stream.
+        if (!sc.work) return hipErrorInvalidValue;
+        unsigned long long* work = sc.work;
         hipError_t e = hipMemsetAsync(work, 0, kWorkWords * sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;
         // chunk size: the option is the maximum; smaller buffers get smaller chunks (down to one wave's worth), so that
@@ -1053,13 +1069,16 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
             while ((uint64_t)fit * 2 <= want && fit * 2 <= strip) fit *= 2;
             strip = fit;
         }
+        const int lds_cap = sc.lds_cap;
+        int* d_spill = sc.spill;
         const bool capped = mode == kBvh4q && d_spill && lds_cap >= 2 && s.stack_depth + 2 > (uint32_t)lds_cap;
         const size_t lds = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
         const uint64_t n_chunks = (n + strip - 1) / strip;
         // a full grid when there are chunks for it (>= 8 per wave by the chunk size above, down to 1 for small buffers,
-        // where putting every ray in flight at once matters more than the tail)
-        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));
+        // where putting every ray in flight at once matters more than the tail); sc.max_blocks bounds the spill columns
+        uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));
+        if (sc.max_blocks) blocks = std::min<uint64_t>(blocks, sc.max_blocks);
         dim3 g((uint32_t)blocks);
 #define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M, P) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P); else RT_LAUNCH(M, true, false, P); } \

@@ -16,6 +16,7 @@ struct DevScene {
     const uint32_t* sphere_mat;  // material id per sphere; triangles keep theirs in normals[3*i].w
     const float4* lights;    // 2 x float4 per light: (position, intensity) (colour, 0)
     uint32_t n_nodes, n_tris, n_spheres, stack_depth, n_lights;
+    float ray_pad;           // per-ray box pad = ray_pad * max|origin coordinate| (kernels.hip make_slab); 2^-pad_log2, 0 = off
 };
 
 // Camera constants precomputed on the host by rt_set_camera (frag.glsl:106-110: tan of the half fov
@@ -36,21 +37,27 @@ constexpr uint32_t kBins = kBinCells + 1;
 constexpr uint32_t kBinBlocksMax = 1024;
 struct BinGrid { float lox, loy, loz, sx, sy, sz; };        // cell = clamp((o - lo) * s, 0, 15)
 // scratch words (uint32) that launch_bin needs for n rays: the permutation + per-block histograms
-inline uint64_t bin_scratch_words(uint64_t n) { return n + (uint64_t)kBinBlocksMax * kBins + kBins + 4; }
+inline uint64_t bin_scratch_words(uint64_t n, uint32_t max_blocks = kBinBlocksMax) { return n + (uint64_t)max_blocks * kBins + kBins + 4; }
 // word 0 behind the bin totals: 1 if the permutation is to be used (see launch_bin), 0 if the input was coherent already
-inline const uint32_t* bin_flag(const uint32_t* d_scratch, uint64_t n) { return d_scratch + n + (uint64_t)kBinBlocksMax * kBins + kBins; }
+inline const uint32_t* bin_flag(const uint32_t* d_scratch, uint64_t n, uint32_t max_blocks = kBinBlocksMax) { return d_scratch + n + (uint64_t)max_blocks * kBins + kBins; }
 // d_scratch[0 .. n) receives the permutation (ray indices grouped by bin); n must be < 2^32
 // min_run: the rays are only permuted when a (64 Ki-ray block, cell) pair holds fewer than min_run rays on average,
 // i.e. when the buffer is not grouped by origin already (0 = always permute).  The decision is taken on the device.
-hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st);
+// max_blocks: histogram rows the scratch was sized for (bin_scratch_words with the same value)
+hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st,
+                      uint32_t max_blocks = kBinBlocksMax);
 
+// Scratch of one strip-kernel launch (the caller owns it and keeps launches that share it ordered):
+//   work       kWorkWords u64: 8 chunk cursors + the mask of exhausted eighths, kCursorStride apart (zeroed by launch_trace)
+//   spill      BVH4q: spill_words() ints, enables the capped LDS stack (null = whole stack in LDS)
+//   lds_cap    stack entries per lane kept in LDS when spill is given
+//   max_blocks bound on the persistent grid (0 = none): the spill area holds one column per thread of the grid
+struct StripScratch { unsigned long long* work = nullptr; int* spill = nullptr; int lds_cap = 0; uint32_t max_blocks = 0; };
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
                         uint32_t strip /* rays per chunk, 0 = one ray per lane */, int refill /* idle lanes that trigger a refill */,
-                        const uint32_t* d_perm = nullptr /* order in which rays are handed out (strip kernel only) */,
-                        const uint32_t* d_perm_on = nullptr /* device flag: 0 = ignore d_perm */,
-                        int* d_spill = nullptr /* strip kernel, BVH4q: spill_words() ints; enables the capped LDS stack */,
-                        int lds_cap = 0 /* stack entries kept in LDS when d_spill is given */);
+                        const uint32_t* d_perm /* order in which rays are handed out (strip kernel only) or null */,
+                        const uint32_t* d_perm_on /* device flag: 0 = ignore d_perm */, const StripScratch& sc);
 
 // Capped LDS stack of the strip kernel (kernels.hip "Capped stack"): entries beyond lds_cap spill to global memory,
 // one column per thread of the persistent grid (at most 8 blocks of kThreads per CU).
@@ -90,7 +97,7 @@ hipError_t launch_shade_resolve(const DevScene& s, int mode, const rt_ray* d_ray
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
 
 constexpr int kStackDepth = 32;   // BVH2 depth budget + 2: bounds the per-lane traversal stack of the BVH2 layout
-constexpr int kWorkSlots = 64;    // ring of chunk-cursor sets (8 cursors each) of the strip kernel, stored behind the counters (one set per launch in flight)
+constexpr int kWorkSlots = 4;     // chunk-cursor sets behind the counters: one per scratch slot of a replica (rt_api.cpp)
 constexpr int kCursorStride = 16;       // u64 words between chunk cursors: one 128-B line each, so they sit in different L2 channels
 constexpr int kWorkWords = 9 * kCursorStride;   // 8 cursors + the mask of exhausted eighths
 constexpr int kCountersPad = 16;        // the counters take the first line of the buffer, the cursor sets follow

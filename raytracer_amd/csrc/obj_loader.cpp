@@ -10,6 +10,7 @@
 // every triangle gets the one material the caller passes.
 #include "../../include/raytracer_amd.h"
 #include "../host/rt_types.hpp"
+#include "abi_guard.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -52,11 +53,12 @@ bool resolve(long idx, size_t count, size_t& out) {
 
 }  // namespace
 
-extern "C" int rt_load_obj(const char* path, const void* material48, void* tris144, uint64_t cap, uint64_t* n_tris_out) {
+extern "C" int rt_load_obj(const char* path, const void* material48, void* tris144, uint64_t cap, uint64_t* n_tris_out) try {
     if (!path || !n_tris_out) return RT_E_INVALID;
     *n_tris_out = 0;
     std::FILE* f = std::fopen(path, "rb");
     if (!f) return RT_E_INVALID;
+    struct Closer { std::FILE* f; ~Closer() { std::fclose(f); } } closer{ f };     // also when a vector throws
     Material mat;
     std::memset(&mat, 0, sizeof mat);
     if (material48) std::memcpy(&mat, material48, sizeof mat);
@@ -120,7 +122,8 @@ extern "C" int rt_load_obj(const char* path, const void* material48, void* tris1
             if (rc != RT_OK) break;
         }
     }
-    std::fclose(f);
     *n_tris_out = n;
     return rc;
+} catch (...) {
+    return rt::abi_exception(nullptr);       // RT_E_NOMEM for std::bad_alloc
 }

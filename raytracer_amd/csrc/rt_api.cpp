@@ -5,18 +5,24 @@
 // reference are cited next to each declaration in the header.
 #include "../../include/raytracer_amd.h"
 #include "../host/rt_types.hpp"
+#include "abi_guard.hpp"
 #include "bvh.hpp"
 #include "kernels.hpp"
+#include "scene_host.hpp"
 
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <array>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,7 +31,77 @@ using namespace rt;
 
 namespace {
 
-constexpr uint64_t kChunkRays = 1ull << 22;   // host-pointer entry points stream rays in 4 Mi-ray pieces
+constexpr uint64_t kPieceRays = 1ull << 21;   // host-pointer entry points stream rays in 2 Mi-ray pieces (64 MB in, 32 MB out)
+constexpr int kPipeRing = 3;                  // pieces in flight: staging copy | H2D + kernel | D2H + copy-out
+constexpr uint32_t kSpillSlots = 4;           // strip-kernel scratch sets (cursors + spill columns) of one slot, used round-robin
+constexpr int kEvBin = kSpillSlots, kEvPrim = kSpillSlots + 1, kNumScratchEvents = kSpillSlots + 2;
+
+// Splits one large memcpy over a few persistent host threads: a single thread moves ~10 GB/s between pageable and pinned
+// memory, a fifth of what the PCIe link takes.  Used by the host-pointer entry points only.
+class CopyPool {
+public:
+    explicit CopyPool(unsigned helpers) {
+        th_.reserve(helpers);
+        try { for (unsigned k = 0; k < helpers; ++k) th_.emplace_back([this] { worker(); }); }
+        catch (...) {}                                 // fewer helpers; the caller's thread always takes part
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> g(mu_); quit_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void copy(void* dst, const void* src, size_t bytes) {
+        const size_t parts = th_.size() + 1, min_part = 1u << 20;
+        if (th_.empty() || bytes < 2 * min_part) { std::memcpy(dst, src, bytes); return; }
+        const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes; per_ = per;
+            next_ = 1; todo_ = (int)th_.size(); ++gen_;
+        }
+        cv_.notify_all();
+        std::memcpy(dst, src, std::min(per, bytes));                                       // part 0 on this thread
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [&] { return todo_ == 0; });
+    }
+private:
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            size_t part;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return quit_ || gen_ != seen; });
+                if (quit_) return;
+                seen = gen_;
+                part = next_++;
+            }
+            const size_t b = part * per_;
+            if (b < bytes_) std::memcpy(dst_ + b, src_ + b, std::min(per_, bytes_ - b));
+            { std::lock_guard<std::mutex> g(mu_); if (--todo_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    char* dst_ = nullptr; const char* src_ = nullptr;
+    size_t bytes_ = 0, per_ = 0, next_ = 0;
+    int todo_ = 0;
+    uint64_t gen_ = 0;
+    bool quit_ = false;
+};
+
+// Staging of the host-pointer entry points (rt_trace / rt_occluded): pinned host buffers and device buffers for
+// kPipeRing pieces, two streams, one event per ring slot.
+struct HostPipe {
+    void* pin_in[kPipeRing] = {};  void* pin_out[kPipeRing] = {};
+    void* d_in[kPipeRing] = {};    void* d_out[kPipeRing] = {};
+    hipEvent_t done[kPipeRing] = {};
+    hipStream_t st[2] = {};
+    uint64_t cap_rays = 0;
+    bool ready = false;
+    std::unique_ptr<CopyPool> pool;            // staging copies (created on first use)
+};
 
 struct Replica {
     int device = 0;
@@ -39,18 +115,31 @@ struct Replica {
     float4* d_lights = nullptr;
     // scratch for rt_render
     void* d_render = nullptr; size_t render_cap = 0;
-    unsigned long long* d_counters = nullptr;
-    // scratch for host-pointer entry points
-    void* d_rays = nullptr;  size_t rays_cap = 0;
+    unsigned long long* d_counters = nullptr;      // kCountersPad words of counters, then kSpillSlots cursor sets
+    // scratch for rt_trace_primary
     void* d_out = nullptr;   size_t out_cap = 0;
     // scratch for ray binning (permutation + histograms, uint32 words)
     uint32_t* d_bin = nullptr; uint64_t bin_cap = 0;
-    // spill area of the strip kernel's capped stack: kSpillSlots buffers used round-robin (launches in flight)
-    int* d_spill = nullptr; uint64_t spill_cap = 0; uint32_t spill_seq = 0;
+    // spill area of the strip kernel's capped stack: kSpillSlots buffers used round-robin with the cursor sets
+    int* d_spill = nullptr; uint64_t spill_cap = 0; uint32_t scratch_seq = 0;
     // primary rays / hits of the ray-buffer primary path when the caller does not ask for them
     void* d_prim = nullptr; size_t prim_cap = 0;
+    // Launches of one slot share the scratch above.  Stream order protects launches on one stream; for launches on
+    // different streams every scratch piece has an event: recorded after its last user, waited on (on the device)
+    // by its next user.  Any number of launches may therefore be in flight on any streams.
+    hipEvent_t sc_ev[kNumScratchEvents] = {};
+    bool sc_used[kNumScratchEvents] = {};
+    HostPipe pipe;
     std::string err;
 };
+
+hipError_t scratch_acquire(Replica& r, int k, hipStream_t st) {
+    return r.sc_used[k] ? hipStreamWaitEvent(st, r.sc_ev[k], 0) : hipSuccess;
+}
+hipError_t scratch_release(Replica& r, int k, hipStream_t st) {
+    r.sc_used[k] = true;
+    return hipEventRecord(r.sc_ev[k], st);
+}
 
 double now_ms() {
     using namespace std::chrono;
@@ -61,12 +150,14 @@ double now_ms() {
 
 struct rt_ctx {
     std::vector<Replica> reps;
+    std::vector<void*> host_blocks;   // rt_host_alloc
     std::string err;
     // options
     int traversal = 0;          // 0 auto, 1 brute force, 2 BVH2 nodes, 3 BVH4q nodes (RT_OPT_TRAVERSAL)
     int bvh_threads = 0;
     int counters = 0;
-    int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2
+    int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2; the per-ray pad uses the same factor
+    int ray_pad = 1;            // per-ray box pad (kernels.hip make_slab): 1 on, 0 off (measurement only: far origins then lose hits)
     int max_leaf = 4;
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
@@ -92,6 +183,7 @@ struct rt_ctx {
         s.n_lights = stats.n_lights;
         s.n_nodes = stats.n_nodes; s.n_tris = stats.n_tris; s.n_spheres = stats.n_spheres;
         s.stack_depth = stack_need;
+        s.ray_pad = ray_pad ? std::ldexp(1.0f, -pad_log2) : 0.0f;
         return s;
     }
 };
@@ -127,45 +219,62 @@ void free_scene(Replica& r) {
 // (launch_bin), which keeps a wave's node fetches close together when the structure does not fit the L2s.
 constexpr uint64_t kBinMinRays = 1ull << 18;
 constexpr uint64_t kBinMinSceneBytes = 48ull << 20;
-constexpr uint32_t kSpillSlots = 4;       // strip launches of one slot that may be in flight at once
 constexpr uint32_t kBinMinRun = 128;      // mean rays per non-empty (64 Ki-ray block, cell) pair above which a buffer counts as coherent
+bool wants_binning(const rt_ctx* c, int mode, uint64_t n) {
+    const uint64_t scene_bytes = (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48;
+    return mode != kBrute && c->strip >= 64 && n >= kBinMinRays && n < (1ull << 32) &&
+           (c->binning == 1 || (c->binning == 2 && scene_bytes > kBinMinSceneBytes));
+}
 hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
                       uint8_t* d_occ, hipStream_t st) {
+    if (n == 0) return hipSuccess;
     const int mode = c->mode();
-    const uint64_t scene_bytes = (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48;
-    const bool bin = mode != kBrute && c->strip >= 64 && n >= kBinMinRays && n < (1ull << 32) &&
-                     (c->binning == 1 || (c->binning == 2 && scene_bytes > kBinMinSceneBytes));
+    const bool strip_kernel = mode != kBrute && c->strip >= 64;
+    const bool bin = wants_binning(c, mode, n);
     const uint32_t* perm = nullptr;
+    hipError_t e;
     if (bin) {
         const uint64_t words = bin_scratch_words(n);
         if (words > r.bin_cap) {
-            if (r.d_bin) (void)hipFree(r.d_bin);
+            if (r.d_bin) (void)hipFree(r.d_bin);          // hipFree waits for the device: no launch still reads it
             r.d_bin = nullptr; r.bin_cap = 0;
-            hipError_t e = hipMalloc(reinterpret_cast<void**>(&r.d_bin), words * sizeof(uint32_t));
+            e = hipMalloc(reinterpret_cast<void**>(&r.d_bin), words * sizeof(uint32_t));
             if (e != hipSuccess) return e;
             r.bin_cap = words;
         }
+        if ((e = scratch_acquire(r, kEvBin, st)) != hipSuccess) return e;
         // auto: permute only buffers that are not grouped by origin already (camera-ordered bounce rays are)
-        hipError_t e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, c->binning == 1 ? 0u : kBinMinRun, st);
+        e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, c->binning == 1 ? 0u : kBinMinRun, st);
         if (e != hipSuccess) return e;
         perm = r.d_bin;
     }
-    int* spill = nullptr;
-    if (mode == kBvh4q && c->strip >= 64) {
-        const uint64_t words = c->lds_stack ? spill_words(c->stack_need, c->lds_stack, device_cus()) : 0;
-        if (words) {
-            if (words * kSpillSlots > r.spill_cap) {
-                if (r.d_spill) (void)hipFree(r.d_spill);
-                r.d_spill = nullptr; r.spill_cap = 0;
-                hipError_t e = hipMalloc(reinterpret_cast<void**>(&r.d_spill), words * kSpillSlots * sizeof(int));
-                if (e != hipSuccess) return e;
-                r.spill_cap = words * kSpillSlots;
+    StripScratch sc;
+    int set = -1;
+    if (strip_kernel) {
+        set = (int)(r.scratch_seq++ % kSpillSlots);
+        sc.work = r.d_counters + kCountersPad + (size_t)set * kWorkWords;
+        sc.lds_cap = c->lds_stack;
+        if (mode == kBvh4q) {
+            const uint64_t words = c->lds_stack ? spill_words(c->stack_need, c->lds_stack, device_cus()) : 0;
+            if (words) {
+                if (words * kSpillSlots > r.spill_cap) {
+                    if (r.d_spill) (void)hipFree(r.d_spill);
+                    r.d_spill = nullptr; r.spill_cap = 0;
+                    e = hipMalloc(reinterpret_cast<void**>(&r.d_spill), words * kSpillSlots * sizeof(int));
+                    if (e != hipSuccess) return e;
+                    r.spill_cap = words * kSpillSlots;
+                }
+                sc.spill = r.d_spill + (uint64_t)set * words;
             }
-            spill = r.d_spill + (uint64_t)(r.spill_seq++ % kSpillSlots) * words;
         }
+        if ((e = scratch_acquire(r, set, st)) != hipSuccess) return e;
     }
-    return launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm,
-                        perm ? bin_flag(perm, n) : nullptr, spill, c->lds_stack);
+    e = launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm,
+                     perm ? bin_flag(perm, n) : nullptr, sc);
+    if (e != hipSuccess) return e;
+    if (set >= 0 && (e = scratch_release(r, set, st)) != hipSuccess) return e;
+    if (bin && (e = scratch_release(r, kEvBin, st)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 // Primary rays of a "hard" tree go through the ray-buffer kernel (ray generation -> k_trace_strip).  What decides is
@@ -209,8 +318,13 @@ int for_each_slot(rt_ctx* c, F fn) {
     if (n == 1) {
         rc[0] = fn(0);
     } else {
+        // nothing may escape a std::thread; a thread that cannot be started runs its slot on this one
+        auto run = [&](int s) { try { rc[s] = fn(s); } catch (...) { rc[s] = abi_exception(&c->reps[s].err); } };
         std::vector<std::thread> th;
-        for (int s = 0; s < n; ++s) th.emplace_back([&, s] { rc[s] = fn(s); });
+        th.reserve(n);
+        for (int s = 0; s < n; ++s) {
+            try { th.emplace_back(run, s); } catch (...) { run(s); }
+        }
         for (auto& t : th) t.join();
     }
     for (int s = 0; s < n; ++s)
@@ -228,51 +342,73 @@ int slot_fail(Replica& r, hipError_t e, const char* what) {
         if (e__ != hipSuccess) return slot_fail((r), e__, #call);      \
     } while (0)
 
+// Handler of every entry point's function-try-block: nothing is thrown across the ABI (abi_guard.hpp).
+#define RT_ABI_CATCH(ctx) catch (...) { rt_ctx* c__ = const_cast<rt_ctx*>(static_cast<const rt_ctx*>(ctx)); return abi_exception(c__ ? &c__->err : nullptr); }
+
+void free_pipe(Replica& r) {
+    HostPipe& p = r.pipe;
+    p.pool.reset();
+    for (int k = 0; k < kPipeRing; ++k) {
+        if (p.pin_in[k]) (void)hipHostFree(p.pin_in[k]);
+        if (p.pin_out[k]) (void)hipHostFree(p.pin_out[k]);
+        if (p.d_in[k]) (void)hipFree(p.d_in[k]);
+        if (p.d_out[k]) (void)hipFree(p.d_out[k]);
+        if (p.done[k]) (void)hipEventDestroy(p.done[k]);
+        p.pin_in[k] = p.pin_out[k] = p.d_in[k] = p.d_out[k] = nullptr; p.done[k] = nullptr;
+    }
+    for (int k = 0; k < 2; ++k) { if (p.st[k]) (void)hipStreamDestroy(p.st[k]); p.st[k] = nullptr; }
+    p.cap_rays = 0; p.ready = false;
+}
+
 }  // namespace
 
 extern "C" {
 
-int rt_create(rt_ctx** out, const int* device_ids, int n_devices) {
+int rt_create(rt_ctx** out, const int* device_ids, int n_devices) try {
     if (!out) return RT_E_INVALID;
     *out = nullptr;
     if (n_devices < 1 || n_devices > 64) return RT_E_INVALID;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return RT_E_DEVICE;
-    rt_ctx* c = new (std::nothrow) rt_ctx();
-    if (!c) return RT_E_NOMEM;
+    std::unique_ptr<rt_ctx> c(new rt_ctx());
     c->reps.resize(n_devices);
+    const size_t counter_words = kCountersPad + (size_t)kSpillSlots * kWorkWords;
+    static_assert(kWorkSlots == (int)kSpillSlots, "one cursor set per scratch slot");
     for (int i = 0; i < n_devices; ++i) {
         int d = device_ids ? device_ids[i] : i;
-        if (d < 0 || d >= ndev) { delete c; return RT_E_INVALID; }
+        if (d < 0 || d >= ndev) { rt_destroy(c.release()); return RT_E_INVALID; }
         Replica& r = c->reps[i];
         r.device = d;
-        if (hipSetDevice(d) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipMalloc(&r.d_counters, (kCountersPad + (size_t)kWorkSlots * kWorkWords) * sizeof(unsigned long long)) != hipSuccess ||
-            hipMemset(r.d_counters, 0, (kCountersPad + (size_t)kWorkSlots * kWorkWords) * sizeof(unsigned long long)) != hipSuccess) {
-            rt_destroy(c);
-            return RT_E_DEVICE;
-        }
+        bool ok = hipSetDevice(d) == hipSuccess && hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipMalloc(&r.d_counters, counter_words * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMemset(r.d_counters, 0, counter_words * sizeof(unsigned long long)) == hipSuccess;
+        for (int k = 0; ok && k < kNumScratchEvents; ++k) ok = hipEventCreateWithFlags(&r.sc_ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { rt_destroy(c.release()); return RT_E_DEVICE; }
     }
-    *out = c;
+    *out = c.release();
     return RT_OK;
+} catch (...) {
+    return abi_exception(nullptr);
 }
 
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
     for (Replica& r : c->reps) {
         (void)hipSetDevice(r.device);
-        if (r.stream) (void)hipStreamSynchronize(r.stream);
+        (void)hipDeviceSynchronize();            // *_dev launches may still be running on the caller's streams
         free_scene(r);
+        free_pipe(r);
         if (r.d_counters) (void)hipFree(r.d_counters);
-        if (r.d_rays) (void)hipFree(r.d_rays);
         if (r.d_out) (void)hipFree(r.d_out);
         if (r.d_bin) (void)hipFree(r.d_bin);
         if (r.d_spill) (void)hipFree(r.d_spill);
         if (r.d_prim) (void)hipFree(r.d_prim);
         if (r.d_render) (void)hipFree(r.d_render);
+        for (hipEvent_t ev : r.sc_ev) if (ev) (void)hipEventDestroy(ev);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
+    for (void* p : c->host_blocks) (void)hipHostFree(p);
     delete c;
 }
 
@@ -280,7 +416,7 @@ const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null c
 
 int rt_num_slots(const rt_ctx* c) { return c ? (int)c->reps.size() : 0; }
 
-int rt_set_option(rt_ctx* c, int key, int64_t v) {
+int rt_set_option(rt_ctx* c, int key, int64_t v) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     switch (key) {
@@ -290,17 +426,19 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) {
         case RT_OPT_LDS_STACK:   if (v != 0 && (v < 2 || v > 64)) return fail(c, RT_E_INVALID, "RT_OPT_LDS_STACK: 0 or 2..64 entries"); c->lds_stack = (int)v; return RT_OK;
         case RT_OPT_PRIMARY:     if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_PRIMARY: 0 auto, 1 tile kernel, 2 ray-buffer kernel"); c->primary_path = (int)v; return RT_OK;
         case RT_OPT_RAY_BINNING: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_RAY_BINNING: 0 off, 1 on, 2 auto"); c->binning = (int)v; return RT_OK;
-        case RT_OPT_PAD_LOG2:    if (v < 4 || v > 64) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,64]"); c->pad_log2 = (int)v; return RT_OK;
+        // 2^-4 .. 2^-20: below 2^-20 (16 ulp) the conservative-traversal argument of DESIGN.md no longer holds
+        case RT_OPT_PAD_LOG2:    if (v < 4 || v > 20) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,20]"); c->pad_log2 = (int)v; return RT_OK;
         case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;
         case RT_OPT_STRIP:       if (v != 0 && (v < 64 || v > (1 << 24))) return fail(c, RT_E_INVALID, "RT_OPT_STRIP: 0 or 64..2^24"); c->strip = (uint32_t)v; return RT_OK;
         case RT_OPT_REFILL:      if ((v & 0xff) < 1 || (v & 0xff) > 64 || (v >> 8) > 64) return fail(c, RT_E_INVALID, "RT_OPT_REFILL: low byte 1..64 idle lanes, bits 8.. = leaf-vote threshold 0..64"); c->refill = (int)v; return RT_OK;
+        case RT_OPT_RAY_PAD:     if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PAD: 0 off, 1 on"); c->ray_pad = (int)v; return RT_OK;
         default: return fail(c, RT_E_INVALID, "unknown option key");
     }
-}
+} RT_ABI_CATCH(c)
 
 int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_stride, const void* spheres,
                     uint32_t n_spheres, uint32_t sphere_stride, const void* lights, uint32_t n_lights,
-                    uint32_t light_stride) {
+                    uint32_t light_stride) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (n_tris && (!tris || tri_stride < sizeof(Triangle) || (tri_stride & 3))) return fail(c, RT_E_INVALID, "triangles: null pointer or stride < 144 / not a multiple of 4");
@@ -310,219 +448,71 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     if (n_spheres >= (1u << 31)) return fail(c, RT_E_TOO_LARGE, "more than 2^31-1 spheres");
 
     const double t0 = now_ms();
-    // 1. exact triangle bounds (positions at byte offsets 0 / 32 / 64 of the 144-B struct)
-    std::vector<Aabb> boxes(n_tris);
-    float maxabs = 0.f;
-    const char* tb = static_cast<const char*>(tris);
-    Aabb scene_box; scene_box.reset();
-    for (uint32_t i = 0; i < n_tris; ++i) {
-        const char* t = tb + (size_t)i * tri_stride;
-        Aabb b; b.reset();
-        for (int v = 0; v < 3; ++v) {
-            float p[3];
-            std::memcpy(p, t + 32 * v, 12);
-            for (int a = 0; a < 3; ++a) {
-                if (!std::isfinite(p[a])) return fail(c, RT_E_INVALID, "triangle " + std::to_string(i) + " has a non-finite position");
-                maxabs = std::max(maxabs, std::fabs(p[a]));
-            }
-            b.grow(p);
-        }
-        boxes[i] = b;
-        scene_box.grow(b);
+    // host half (scene_host.cpp): bounds, BVH build, flatten, device records.  Traversal option 2 asks for the plain
+    // BVH2 layout; everything else gets the 4-wide quantised one (faster on every measured config, scripts/cmp_layouts.py)
+    HostSceneParams hp;
+    hp.layout = (c->traversal == 2) ? kBvh2 : kBvh4q;
+    hp.max_leaf = c->max_leaf; hp.pad_log2 = c->pad_log2; hp.threads = c->bvh_threads; hp.max_depth = kStackDepth - 2;
+    HostScene hs;
+    {
+        std::string err;
+        const int rc = prepare_scene(tris, n_tris, tri_stride, spheres, n_spheres, sphere_stride, lights, n_lights, light_stride, hp, hs, err);
+        if (rc != RT_OK) return fail(c, rc, err);
     }
-    // 2. BVH2 build + flatten
-    BuildParams bp;
-    bp.max_leaf = c->max_leaf;
-    bp.max_depth = kStackDepth - 2;
-    bp.threads = c->bvh_threads;
-    BuildResult br;
-    build_bvh2(boxes.data(), n_tris, bp, br);
-    for (const BuildNode& nd : br.nodes)
-        if (nd.count > 8) return fail(c, RT_E_TOO_LARGE, "internal: leaf with more than 8 triangles (depth budget exceeded)");
-    // traversal option 2 asks for the plain BVH2 layout; everything else gets the 4-wide quantised one (faster on
-    // every measured config since the sign-selected plane test, scripts/cmp_layouts.py)
-    int layout = (c->traversal == 2) ? kBvh2 : kBvh4q;
-    const float pad = std::ldexp(std::max(maxabs, 1e-30f), -c->pad_log2);
-    struct { std::vector<float> nodes; std::vector<uint32_t> tri_order; uint32_t n_nodes = 0, n_leaves = 0, depth = 0, stack_need = 0; } flat;
-    if (layout == kBvh4q) {
-        FlatBvh4q f4;
-        flatten_bvh4q(br, n_tris ? pad : 0.f, f4);
-        if (f4.stack_need + 2 > 64) {
-            layout = kBvh2;                     // pathological tree: its 4-wide stack would not fit 64 KB of LDS
-        } else {
-            flat.nodes.resize(f4.nodes.size());
-            if (!f4.nodes.empty()) std::memcpy(flat.nodes.data(), f4.nodes.data(), f4.nodes.size() * 4);
-            flat.tri_order.swap(f4.tri_order);
-            flat.n_nodes = f4.n_nodes; flat.n_leaves = f4.n_leaves; flat.depth = f4.depth; flat.stack_need = f4.stack_need;
-        }
-    }
-    if (layout == kBvh2) {
-        FlatBvh2 f2;
-        flatten_bvh2(br, n_tris ? pad : 0.f, f2);
-        flat.nodes.swap(f2.nodes); flat.tri_order.swap(f2.tri_order);
-        flat.n_nodes = f2.n_nodes; flat.n_leaves = f2.n_leaves; flat.depth = f2.depth;
-        flat.stack_need = std::max(f2.depth, bvh2_stack_need(br));
-    }
-    if (flat.stack_need + 2 > 64) return fail(c, RT_E_TOO_LARGE, "internal: traversal stack would exceed the LDS budget");
-
-    // 3. device records
-    std::vector<float> tri48((size_t)n_tris * 12), nrm48((size_t)n_tris * 12), sph((size_t)n_spheres * 4);
-    for (uint32_t k = 0; k < n_tris; ++k) {
-        const uint32_t id = flat.tri_order[k];
-        const char* t = tb + (size_t)id * tri_stride;
-        float p0[3], p1[3], p2[3];
-        std::memcpy(p0, t, 12); std::memcpy(p1, t + 32, 12); std::memcpy(p2, t + 64, 12);
-        float* o = &tri48[(size_t)k * 12];
-        o[0] = p0[0]; o[1] = p0[1]; o[2] = p0[2]; std::memcpy(&o[3], &id, 4);
-        // frag.glsl:132-133: edge1 = v1 - v0, edge2 = v2 - v0 (plain fp32 subtraction, no contraction possible)
-        o[4] = p1[0] - p0[0]; o[5] = p1[1] - p0[1]; o[6] = p1[2] - p0[2]; o[7] = 0.f;
-        o[8] = p2[0] - p0[0]; o[9] = p2[1] - p0[1]; o[10] = p2[2] - p0[2]; o[11] = 0.f;
-    }
-    // distinct materials (src/math/Material.h:6-11, 9 floats used) -> table; ids ride in normals[3*i].w / sphere_mat
-    std::vector<float> mats;                       // 12 floats per material: (albedo, strength) (emission, roughness) (metallic,0,0,0)
-    std::map<std::array<uint32_t, 9>, uint32_t> mat_ids;
-    auto material_id = [&](const char* m48) -> uint32_t {
-        float f[10];
-        std::memcpy(f, m48, 40);                   // albedo@0, emission@16, strength@28, roughness@32, metallic@36
-        std::array<uint32_t, 9> key;
-        const float vals[9] = { f[0], f[1], f[2], f[4], f[5], f[6], f[7], f[8], f[9] };
-        std::memcpy(key.data(), vals, 36);
-        auto it = mat_ids.find(key);
-        if (it != mat_ids.end()) return it->second;
-        const uint32_t id = (uint32_t)mat_ids.size();
-        mat_ids.emplace(key, id);
-        const float rec[12] = { f[0], f[1], f[2], f[7], f[4], f[5], f[6], f[8], f[9], 0.f, 0.f, 0.f };
-        mats.insert(mats.end(), rec, rec + 12);
-        return id;
-    };
-    for (uint32_t i = 0; i < n_tris; ++i) {
-        const char* t = tb + (size_t)i * tri_stride;
-        float* o = &nrm48[(size_t)i * 12];
-        for (int v = 0; v < 3; ++v) { std::memcpy(o + 4 * v, t + 16 + 32 * v, 12); o[4 * v + 3] = 0.f; }
-        const uint32_t id = material_id(t + 96);
-        std::memcpy(&o[3], &id, 4);
-    }
-    std::vector<float> sphere_mat((size_t)n_spheres), lights8((size_t)n_lights * 8);
-    for (uint32_t i = 0; i < n_spheres; ++i) {
-        const uint32_t id = material_id(static_cast<const char*>(spheres) + (size_t)i * sphere_stride + 16);
-        std::memcpy(&sphere_mat[i], &id, 4);
-    }
-    for (uint32_t i = 0; i < n_lights; ++i) {      // src/math/Light.h:6-10: position@0, colour@16, intensity@28
-        const char* l = static_cast<const char*>(lights) + (size_t)i * light_stride;
-        float* o = &lights8[(size_t)i * 8];
-        std::memcpy(o, l, 12); std::memcpy(o + 3, l + 28, 4);
-        std::memcpy(o + 4, l + 16, 12); o[7] = 0.f;
-    }
-    const char* sb = static_cast<const char*>(spheres);
-    for (uint32_t i = 0; i < n_spheres; ++i) std::memcpy(&sph[(size_t)i * 4], sb + (size_t)i * sphere_stride, 16);
     const double t1 = now_ms();
 
-    // 4. replicate
+    // replicate
     c->has_scene = false;
     for (Replica& r : c->reps) {
         RT_HIP(c, hipSetDevice(r.device));
-        RT_HIP(c, hipStreamSynchronize(r.stream));
+        RT_HIP(c, hipDeviceSynchronize());       // launches on any stream may still read the old scene
         free_scene(r);
-        auto up = [&](float4** dst, const std::vector<float>& src) -> hipError_t {
-            const size_t bytes = std::max<size_t>(src.size() * sizeof(float), 64);
+        auto up = [&](float4** dst, const void* src, size_t src_bytes) -> hipError_t {
+            const size_t bytes = std::max<size_t>(src_bytes, 64);
             hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), bytes);
             if (e != hipSuccess) return e;
-            e = hipMemset(*dst, 0, bytes);
-            if (e != hipSuccess || src.empty()) return e;
-            return hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (src_bytes < bytes) { e = hipMemset(*dst, 0, bytes); if (e != hipSuccess) return e; }
+            return src_bytes ? hipMemcpy(*dst, src, src_bytes, hipMemcpyHostToDevice) : hipSuccess;
         };
-        RT_HIP(c, up(&r.d_nodes, flat.nodes));
-        RT_HIP(c, up(&r.d_tris, tri48));
-        RT_HIP(c, up(&r.d_normals, nrm48));
-        RT_HIP(c, up(&r.d_spheres, sph));
-        RT_HIP(c, up(&r.d_materials, mats));
-        RT_HIP(c, up(&r.d_sphere_mat, sphere_mat));
-        RT_HIP(c, up(&r.d_lights, lights8));
+        RT_HIP(c, up(&r.d_nodes, hs.nodes.data(), hs.nodes.size() * 4));
+        RT_HIP(c, up(&r.d_tris, hs.tri48.data(), hs.tri48.size() * 4));
+        RT_HIP(c, up(&r.d_normals, hs.nrm48.data(), hs.nrm48.size() * 4));
+        RT_HIP(c, up(&r.d_spheres, hs.sph.data(), hs.sph.size() * 4));
+        RT_HIP(c, up(&r.d_materials, hs.mats.data(), hs.mats.size() * 4));
+        RT_HIP(c, up(&r.d_sphere_mat, hs.sphere_mat.data(), hs.sphere_mat.size() * 4));
+        RT_HIP(c, up(&r.d_lights, hs.lights8.data(), hs.lights8.size() * 4));
     }
     const double t2 = now_ms();
 
     rt_scene_stats& st = c->stats;
     st = rt_scene_stats{};
     st.n_tris = n_tris; st.n_spheres = n_spheres; st.n_lights = n_lights;
-    st.n_nodes = flat.n_nodes; st.n_leaves = flat.n_leaves; st.max_depth = flat.depth;
-    c->stack_need = flat.stack_need; c->layout = layout;
+    st.n_nodes = hs.n_nodes; st.n_leaves = hs.n_leaves; st.max_depth = hs.depth;
+    c->stack_need = hs.stack_need; c->layout = hs.layout;
     {
         float* lo = &c->bin_grid.lox; float* sc = &c->bin_grid.sx;
         for (int a = 0; a < 3; ++a) {
-            const float ext = n_tris ? scene_box.hi[a] - scene_box.lo[a] : 0.f;
-            lo[a] = n_tris ? scene_box.lo[a] : 0.f;
+            const float ext = n_tris ? hs.box.hi[a] - hs.box.lo[a] : 0.f;
+            lo[a] = n_tris ? hs.box.lo[a] : 0.f;
             sc[a] = ext > 0.f ? 16.0f / ext : 0.f;
         }
     }
     st.node_bytes = 64; st.tri_bytes = 48;
-    st.sah_cost = br.sah_cost;
+    st.sah_cost = hs.sah_cost;
     st.build_ms = (float)(t1 - t0); st.upload_ms = (float)(t2 - t1);
-    st.device_bytes = (uint64_t)flat.nodes.size() * 4 + (uint64_t)tri48.size() * 4 + (uint64_t)nrm48.size() * 4 + (uint64_t)sph.size() * 4;
+    st.device_bytes = (uint64_t)hs.nodes.size() * 4 + (uint64_t)hs.tri48.size() * 4 + (uint64_t)hs.nrm48.size() * 4 + (uint64_t)hs.sph.size() * 4;
     c->has_scene = true;
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
-// Host-only BVH build + flatten (no device): what rt_scene_upload runs before copying to HBM.
-int rt_bvh_build_host(const void* tris, uint32_t n_tris, uint32_t tri_stride, int layout, int max_leaf, int pad_log2,
-                      int threads, rt_scene_stats* stats, uint32_t* nodes_out, uint64_t nodes_cap_words,
-                      uint32_t* tri_order_out) {
-    if (!stats || (n_tris && (!tris || tri_stride < sizeof(Triangle) || (tri_stride & 3)))) return RT_E_INVALID;
-    if (n_tris >= (1u << 28)) return RT_E_TOO_LARGE;
-    if (layout != kBvh2 && layout != kBvh4q) return RT_E_INVALID;
-    const double t0 = now_ms();
-    std::vector<Aabb> boxes(n_tris);
-    float maxabs = 0.f;
-    const char* tb = static_cast<const char*>(tris);
-    for (uint32_t i = 0; i < n_tris; ++i) {
-        Aabb b; b.reset();
-        for (int v = 0; v < 3; ++v) {
-            float p[3];
-            std::memcpy(p, tb + (size_t)i * tri_stride + 32 * v, 12);
-            for (int a = 0; a < 3; ++a) { if (!std::isfinite(p[a])) return RT_E_INVALID; maxabs = std::max(maxabs, std::fabs(p[a])); }
-            b.grow(p);
-        }
-        boxes[i] = b;
-    }
-    BuildParams bp;
-    bp.max_leaf = max_leaf > 0 ? max_leaf : 4;
-    bp.max_depth = kStackDepth - 2;
-    bp.threads = threads;
-    BuildResult br;
-    build_bvh2(boxes.data(), n_tris, bp, br);
-    const float pad = std::ldexp(std::max(maxabs, 1e-30f), -(pad_log2 > 0 ? pad_log2 : 15));
-    *stats = rt_scene_stats{};
-    stats->n_tris = n_tris; stats->sah_cost = br.sah_cost; stats->node_bytes = 64; stats->tri_bytes = 48;
-    std::vector<uint32_t> words, order;
-    if (layout == kBvh2) {
-        FlatBvh2 f; flatten_bvh2(br, n_tris ? pad : 0.f, f);
-        words.resize(f.nodes.size());
-        if (!f.nodes.empty()) std::memcpy(words.data(), f.nodes.data(), f.nodes.size() * 4);
-        order.swap(f.tri_order);
-        stats->n_nodes = f.n_nodes; stats->n_leaves = f.n_leaves; stats->max_depth = f.depth;
-    } else {
-        FlatBvh4q f; flatten_bvh4q(br, n_tris ? pad : 0.f, f);
-        words.swap(f.nodes); order.swap(f.tri_order);
-        stats->n_nodes = f.n_nodes; stats->n_leaves = f.n_leaves; stats->max_depth = f.depth;
-        stats->n_lights = f.stack_need;          // host-only entry: reports the 4-wide stack bound here
-    }
-    stats->build_ms = (float)(now_ms() - t0);
-    stats->device_bytes = (uint64_t)words.size() * 4 + (uint64_t)n_tris * 96;
-    if (nodes_out) {
-        if (nodes_cap_words < words.size()) return RT_E_TOO_LARGE;
-        if (!words.empty()) std::memcpy(nodes_out, words.data(), words.size() * 4);
-    }
-    if (tri_order_out && !order.empty()) std::memcpy(tri_order_out, order.data(), order.size() * 4);
-    return RT_OK;
-}
-
-int rt_scene_stats_get(const rt_ctx* c, rt_scene_stats* out) {
+int rt_scene_stats_get(const rt_ctx* c, rt_scene_stats* out) try {
     if (!c || !out) return RT_E_INVALID;
     if (!c->has_scene) return RT_E_NO_SCENE;
     *out = c->stats;
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
-int rt_set_camera(rt_ctx* c, const void* ubo) {
+int rt_set_camera(rt_ctx* c, const void* ubo) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (!ubo) return fail(c, RT_E_INVALID, "camera: null pointer");
@@ -540,7 +530,7 @@ int rt_set_camera(rt_ctx* c, const void* ubo) {
     c->cam = d;
     c->has_camera = true;
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 // ---- device-resident stages -------------------------------------------------------------------------
 static int check_stage(rt_ctx* c, int slot, bool need_cam) {
@@ -554,7 +544,7 @@ static int check_stage(rt_ctx* c, int slot, bool need_cam) {
 
 int rt_trace_primary_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
                                  uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t seed, int jitter,
-                                 rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) {
+                                 rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) try {
     int rc = check_stage(c, slot, true);
     if (rc) return rc;
     if (!d_hits_out || w == 0 || h == 0 || spp == 0 || stripe_h == 0 || stripe_step == 0) return fail(c, RT_E_INVALID, "primary: bad arguments");
@@ -566,21 +556,24 @@ int rt_trace_primary_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, ui
         const uint64_t n = (uint64_t)rows * w * spp;
         rt_ray* rays = d_rays_out;
         rt_hit* hits = d_hits_out;
+        const bool own = !rays || !hits;            // the slot's scratch stands in for what the caller did not pass
         RT_HIP(c, primary_scratch(r, n, &rays, &hits));
+        if (own) RT_HIP(c, scratch_acquire(r, kEvPrim, st));
         RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, kNone, false, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter,
                                  rays, nullptr, r.d_counters, st));
         RT_HIP(c, trace_rays(c, r, false, false, rays, n, hits, nullptr, st));
+        if (own) RT_HIP(c, scratch_release(r, kEvPrim, st));
         return RT_OK;
     }
     RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), c->counters != 0, w, h, y0, rows, stripe_h, stripe_step,
                              spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_primary_shade_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
                                  uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t seed, int jitter,
                                  uint32_t shade_seed, rt_ray* d_rays_out, rt_hit* d_hits_out, float* d_throughput4,
-                                 float* d_radiance4, rt_ray* d_next_out, void* stream) {
+                                 float* d_radiance4, rt_ray* d_next_out, void* stream) try {
     int rc = check_stage(c, slot, true);
     if (rc) return rc;
     if (!d_throughput4 || !d_radiance4 || w == 0 || h == 0 || spp == 0 || stripe_h == 0 || stripe_step == 0)
@@ -593,28 +586,31 @@ int rt_primary_shade_stripes_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, ui
         const uint64_t n = (uint64_t)rows * w * spp;
         rt_ray* rays = d_rays_out;
         rt_hit* hits = d_hits_out;
+        const bool own = !rays || !hits;
         RT_HIP(c, primary_scratch(r, n, &rays, &hits));
+        if (own) RT_HIP(c, scratch_acquire(r, kEvPrim, st));
         const DevScene ds = c->dev_scene(r);
         RT_HIP(c, launch_primary(ds, c->cam, kNone, false, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, rays, nullptr,
                                  r.d_counters, st));
         RT_HIP(c, trace_rays(c, r, false, false, rays, n, hits, nullptr, st));
         RT_HIP(c, launch_shade(ds, c->mode(), rays, hits, n, (uint32_t)((uint64_t)y0 * w * spp), w * spp, stripe_h, stripe_step, shade_seed,
                                reinterpret_cast<float4*>(d_throughput4), reinterpret_cast<float4*>(d_radiance4), d_next_out, st, true));
+        if (own) RT_HIP(c, scratch_release(r, kEvPrim, st));
         return RT_OK;
     }
     const PrimaryShade ps = { reinterpret_cast<float4*>(d_throughput4), reinterpret_cast<float4*>(d_radiance4), d_next_out, shade_seed };
     RT_HIP(c, launch_primary(c->dev_scene(r), c->cam, c->mode(), false, w, h, y0, rows, stripe_h, stripe_step,
                              spp, seed, jitter, d_rays_out, d_hits_out, r.d_counters, st, &ps));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_trace_primary_dev(rt_ctx* c, int slot, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows, uint32_t spp,
-                         uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) {
+                         uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream) try {
     if (c && (uint64_t)y0 + rows > h) return fail(c, RT_E_INVALID, "primary: y0 + rows > h");
     return rt_trace_primary_stripes_dev(c, slot, w, h, y0, rows, rows ? rows : 1, 1, spp, seed, jitter, d_rays_out, d_hits_out, stream);
-}
+} RT_ABI_CATCH(c)
 
-int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits, void* stream) {
+int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits, void* stream) try {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
     if (n && (!d_rays || !d_hits)) return fail(c, RT_E_INVALID, "trace: null device pointer");
@@ -623,9 +619,9 @@ int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* 
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, trace_rays(c, r, false, c->counters != 0, d_rays, n, d_hits, nullptr, st));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
-int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8_t* d_out, void* stream) {
+int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8_t* d_out, void* stream) try {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
     if (n && (!d_rays || !d_out)) return fail(c, RT_E_INVALID, "occluded: null device pointer");
@@ -634,10 +630,10 @@ int rt_occluded_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, uint8
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, trace_rays(c, r, true, false, d_rays, n, nullptr, d_out, st));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_shadow_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, const float lp[3],
-                  rt_ray* d_srays, uint8_t* d_lit, void* stream) {
+                  rt_ray* d_srays, uint8_t* d_lit, void* stream) try {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
     if (!lp || (n && (!d_rays || !d_hits || !d_lit))) return fail(c, RT_E_INVALID, "shadow: null pointer");
@@ -646,10 +642,10 @@ int rt_shadow_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_shadow(c->dev_scene(r), c->mode(), d_rays, d_hits, n, lp[0], lp[1], lp[2], d_srays, d_lit, st));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_bounce_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
-                  uint32_t seed, rt_ray* d_out, void* stream) {
+                  uint32_t seed, rt_ray* d_out, void* stream) try {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
     if (n && (!d_rays || !d_hits || !d_out)) return fail(c, RT_E_INVALID, "bounce: null device pointer");
@@ -658,16 +654,16 @@ int rt_bounce_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, launch_bounce(c->dev_scene(r), d_rays, d_hits, n, key0, seed, d_out, st));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_shade_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
-                 uint32_t seed, float* d_throughput4, float* d_radiance4, rt_ray* d_out, void* stream) {
+                 uint32_t seed, float* d_throughput4, float* d_radiance4, rt_ray* d_out, void* stream) try {
     return rt_shade_stripes_dev(c, slot, d_rays, d_hits, n, key0, 0, 1, 1, seed, d_throughput4, d_radiance4, d_out, stream);
-}
+} RT_ABI_CATCH(c)
 
 int rt_shade_stripes_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
                          uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step, uint32_t seed, float* d_throughput4,
-                         float* d_radiance4, rt_ray* d_out, void* stream) {
+                         float* d_radiance4, rt_ray* d_out, void* stream) try {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
     if (n && (!d_rays || !d_hits || !d_throughput4 || !d_radiance4)) return fail(c, RT_E_INVALID, "shade: null device pointer");
@@ -676,9 +672,9 @@ int rt_shade_stripes_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit
     RT_HIP(c, launch_shade(c->dev_scene(r), c->mode(), d_rays, d_hits, n, key0, row_len, stripe_h, stripe_step, seed, reinterpret_cast<float4*>(d_throughput4),
                            reinterpret_cast<float4*>(d_radiance4), d_out, (hipStream_t)stream));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
-int rt_path_init_dev(rt_ctx* c, int slot, uint64_t n, float* d_throughput4, float* d_radiance4, void* stream) {
+int rt_path_init_dev(rt_ctx* c, int slot, uint64_t n, float* d_throughput4, float* d_radiance4, void* stream) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
@@ -687,10 +683,10 @@ int rt_path_init_dev(rt_ctx* c, int slot, uint64_t n, float* d_throughput4, floa
     RT_HIP(c, launch_fill(reinterpret_cast<float4*>(d_throughput4), n, 1.f, 1.f, 1.f, 0.f, (hipStream_t)stream));   // frag.glsl:308
     RT_HIP(c, launch_fill(reinterpret_cast<float4*>(d_radiance4), n, 0.f, 0.f, 0.f, 0.f, (hipStream_t)stream));     // :304
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_resolve_dev(rt_ctx* c, int slot, const float* d_radiance4, uint64_t n_pixels, uint32_t spp, float* d_linear4,
-                   uint8_t* d_rgba8, void* stream) {
+                   uint8_t* d_rgba8, void* stream) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
@@ -699,10 +695,10 @@ int rt_resolve_dev(rt_ctx* c, int slot, const float* d_radiance4, uint64_t n_pix
     RT_HIP(c, launch_resolve(reinterpret_cast<const float4*>(d_radiance4), n_pixels, spp, reinterpret_cast<float4*>(d_linear4),
                              reinterpret_cast<uint32_t*>(d_rgba8), (hipStream_t)stream));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 int rt_shade_resolve_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t spp,
-                         float* d_throughput4, float* d_radiance4, float* d_linear4, uint8_t* d_rgba8, void* stream) {
+                         float* d_throughput4, float* d_radiance4, float* d_linear4, uint8_t* d_rgba8, void* stream) try {
     int rc = check_stage(c, slot, false);
     if (rc) return rc;
     if (spp == 0 || n % spp) return fail(c, RT_E_INVALID, "shade+resolve: n must be a multiple of spp");
@@ -722,10 +718,10 @@ int rt_shade_resolve_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit
         RT_HIP(c, launch_resolve(rad, n / spp, spp, reinterpret_cast<float4*>(d_linear4), reinterpret_cast<uint32_t*>(d_rgba8), st));
     }
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 // frag.glsl:303-360 for a whole frame, as a wavefront pipeline: k_primary, then per bounce k_shade + closest hit.
-int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* host_rgba8) {
+int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* host_rgba8) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (!c->has_scene) return fail(c, RT_E_NO_SCENE, "no scene uploaded");
@@ -783,9 +779,9 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
         return RT_OK;
     });
-}
+} RT_ABI_CATCH(c)
 
-int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) {
+int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) try {
     if (!c || !out) return RT_E_INVALID;
     c->err.clear();
     if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
@@ -798,19 +794,19 @@ int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) {
     out->wave_max_nodes = v[5]; out->wave_max_tris = v[6]; out->waves = v[7];
     if (reset) RT_HIP(c, hipMemset(r.d_counters, 0, sizeof v));
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
-int rt_sync(rt_ctx* c, int slot) {
+int rt_sync(rt_ctx* c, int slot) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (!valid_slot(c, slot)) return fail(c, RT_E_INVALID, "slot out of range");
     RT_HIP(c, hipSetDevice(c->reps[slot].device));
     RT_HIP(c, hipDeviceSynchronize());     // *_dev stages may have been enqueued on any stream
     return RT_OK;
-}
+} RT_ABI_CATCH(c)
 
 // ---- host-pointer entry points (blocking; what the reference's single-threaded frame loop expects) ---
-int rt_trace_primary(rt_ctx* c, uint32_t w, uint32_t h, rt_hit* host_out) {
+int rt_trace_primary(rt_ctx* c, uint32_t w, uint32_t h, rt_hit* host_out) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
     if (!c->has_scene) return fail(c, RT_E_NO_SCENE, "no scene uploaded");
@@ -840,8 +836,54 @@ int rt_trace_primary(rt_ctx* c, uint32_t w, uint32_t h, rt_hit* host_out) {
         RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
         return RT_OK;
     });
+} RT_ABI_CATCH(c)
+
+// Is p host memory the GPU can DMA from / to directly (rt_host_alloc, hipHostMalloc)?
+static bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 
+static int pipe_prepare(Replica& r, uint64_t piece, bool stage_in, bool stage_out, size_t osz) {
+    HostPipe& p = r.pipe;
+    if (!p.ready) {
+        for (int k = 0; k < 2; ++k) RT_HIP_SLOT(r, hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking));
+        for (int k = 0; k < kPipeRing; ++k) RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.done[k], hipEventDisableTiming));
+        p.ready = true;
+    }
+    if (piece > p.cap_rays) {                       // device buffers sized for hits (16 B) so that any-hit fits too
+        for (int k = 0; k < kPipeRing; ++k) {
+            if (p.d_in[k]) (void)hipFree(p.d_in[k]);
+            if (p.d_out[k]) (void)hipFree(p.d_out[k]);
+            if (p.pin_in[k]) (void)hipHostFree(p.pin_in[k]);
+            if (p.pin_out[k]) (void)hipHostFree(p.pin_out[k]);
+            p.d_in[k] = p.d_out[k] = p.pin_in[k] = p.pin_out[k] = nullptr;
+        }
+        p.cap_rays = 0;
+        for (int k = 0; k < kPipeRing; ++k) {
+            RT_HIP_SLOT(r, hipMalloc(&p.d_in[k], piece * sizeof(rt_ray)));
+            RT_HIP_SLOT(r, hipMalloc(&p.d_out[k], piece * sizeof(rt_hit)));
+        }
+        p.cap_rays = piece;
+    }
+    (void)osz;
+    for (int k = 0; k < kPipeRing; ++k) {           // pinned staging only for the directions that need it
+        if (stage_in && !p.pin_in[k]) RT_HIP_SLOT(r, hipHostMalloc(&p.pin_in[k], p.cap_rays * sizeof(rt_ray), hipHostMallocDefault));
+        if (stage_out && !p.pin_out[k]) RT_HIP_SLOT(r, hipHostMalloc(&p.pin_out[k], p.cap_rays * sizeof(rt_hit), hipHostMallocDefault));
+    }
+    if ((stage_in || stage_out) && !p.pool) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        p.pool.reset(new CopyPool(std::min(7u, std::max(1u, hw / 2) - 0u)));
+    }
+    return RT_OK;
+}
+
+// Host-pointer closest hit / any-hit (what VkRenderer::drawFrame would call, src/vulkan/VkRenderer.cpp:1287-1374): the
+// rays go through the GPU in pieces of kPieceRays, kPipeRing pieces in flight on two streams, so that the staging copy
+// of piece q+1, the H2D copy + kernel of piece q and the D2H copy of piece q-1 overlap.  Pageable caller memory is
+// staged through pinned buffers by a few host threads; pinned memory (rt_host_alloc / hipHostMalloc) is read and written
+// by DMA directly.
 static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool any_hit) {
     if (!c) return RT_E_INVALID;
     c->err.clear();
@@ -851,42 +893,81 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
     const int ns = (int)c->reps.size();
     const uint64_t per = (n + ns - 1) / ns;
     const size_t osz = any_hit ? 1 : sizeof(rt_hit);
+    const bool stage_in = !is_pinned(rays), stage_out = !is_pinned(out);
     return for_each_slot(c, [&](int s) -> int {
         Replica& r = c->reps[s];
         const uint64_t b = std::min(per * s, n), e = std::min(b + per, n);
         if (e <= b) return RT_OK;
-        const uint64_t chunk = std::min<uint64_t>(kChunkRays, e - b);
+        const uint64_t piece = std::min<uint64_t>(kPieceRays, e - b);
         RT_HIP_SLOT(r, hipSetDevice(r.device));
-        if (chunk * sizeof(rt_ray) > r.rays_cap) {
-            if (r.d_rays) (void)hipFree(r.d_rays);
-            r.d_rays = nullptr; r.rays_cap = 0;
-            RT_HIP_SLOT(r, hipMalloc(&r.d_rays, chunk * sizeof(rt_ray)));
-            r.rays_cap = chunk * sizeof(rt_ray);
+        int rc = pipe_prepare(r, piece, stage_in, stage_out, osz);
+        if (rc != RT_OK) return rc;
+        HostPipe& p = r.pipe;
+        const uint64_t n_pieces = (e - b + piece - 1) / piece;
+        auto first = [&](uint64_t q) { return b + q * piece; };
+        auto count = [&](uint64_t q) { return std::min(piece, e - first(q)); };
+        auto finish = [&](uint64_t q) -> int {               // piece q has left the GPU: hand its results to the caller
+            const int k = (int)(q % kPipeRing);
+            RT_HIP_SLOT(r, hipEventSynchronize(p.done[k]));
+            if (stage_out) p.pool->copy(static_cast<char*>(out) + first(q) * osz, p.pin_out[k], count(q) * osz);
+            return RT_OK;
+        };
+        for (uint64_t q = 0; q < n_pieces; ++q) {
+            const int k = (int)(q % kPipeRing);
+            if (q >= (uint64_t)kPipeRing && (rc = finish(q - kPipeRing)) != RT_OK) return rc;
+            const uint64_t m = count(q);
+            const rt_ray* src = rays + first(q);
+            if (stage_in) { p.pool->copy(p.pin_in[k], src, m * sizeof(rt_ray)); src = static_cast<const rt_ray*>(p.pin_in[k]); }
+            hipStream_t st = p.st[q & 1];
+            RT_HIP_SLOT(r, hipMemcpyAsync(p.d_in[k], src, m * sizeof(rt_ray), hipMemcpyHostToDevice, st));
+            RT_HIP_SLOT(r, trace_rays(c, r, any_hit, false, static_cast<const rt_ray*>(p.d_in[k]), m,
+                                      any_hit ? nullptr : static_cast<rt_hit*>(p.d_out[k]),
+                                      any_hit ? static_cast<uint8_t*>(p.d_out[k]) : nullptr, st));
+            void* dst = stage_out ? p.pin_out[k] : static_cast<void*>(static_cast<char*>(out) + first(q) * osz);
+            RT_HIP_SLOT(r, hipMemcpyAsync(dst, p.d_out[k], m * osz, hipMemcpyDeviceToHost, st));
+            RT_HIP_SLOT(r, hipEventRecord(p.done[k], st));
         }
-        if (chunk * osz > r.out_cap) {
-            if (r.d_out) (void)hipFree(r.d_out);
-            r.d_out = nullptr; r.out_cap = 0;
-            RT_HIP_SLOT(r, hipMalloc(&r.d_out, chunk * osz));
-            r.out_cap = chunk * osz;
-        }
-        for (uint64_t i = b; i < e; i += chunk) {
-            const uint64_t m = std::min(chunk, e - i);
-            RT_HIP_SLOT(r, hipMemcpyAsync(r.d_rays, rays + i, m * sizeof(rt_ray), hipMemcpyHostToDevice, r.stream));
-            RT_HIP_SLOT(r, trace_rays(c, r, any_hit, false, static_cast<const rt_ray*>(r.d_rays), m,
-                                      any_hit ? nullptr : static_cast<rt_hit*>(r.d_out),
-                                      any_hit ? static_cast<uint8_t*>(r.d_out) : nullptr, r.stream));
-            RT_HIP_SLOT(r, hipMemcpyAsync(static_cast<char*>(out) + i * osz, r.d_out, m * osz, hipMemcpyDeviceToHost, r.stream));
-            RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
-        }
+        for (uint64_t q = n_pieces > (uint64_t)kPipeRing ? n_pieces - kPipeRing : 0; q < n_pieces; ++q)
+            if ((rc = finish(q)) != RT_OK) return rc;
         return RT_OK;
     });
 }
 
-int rt_trace(rt_ctx* c, const rt_ray* host_rays, uint64_t n, rt_hit* host_out) {
+// Pinned host memory for the caller's ray / hit arrays (the arrays a renderer keeps for its lifetime, VkRenderer.h:80-90):
+// rt_trace / rt_occluded DMA from and to such buffers directly, without staging copies.  (hipHostRegister of ordinary
+// memory is refused by the driver on the target pool, so the library hands the memory out instead.)
+int rt_host_alloc(rt_ctx* c, size_t bytes, void** out) try {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    if (!out || !bytes) return fail(c, RT_E_INVALID, "host_alloc: null pointer or zero size");
+    *out = nullptr;
+    RT_HIP(c, hipSetDevice(c->reps[0].device));
+    c->host_blocks.reserve(c->host_blocks.size() + 1);
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, RT_E_NOMEM, "host_alloc: out of pinned host memory"); }
+    RT_HIP(c, e);
+    c->host_blocks.push_back(p);
+    *out = p;
+    return RT_OK;
+} RT_ABI_CATCH(c)
+
+int rt_host_free(rt_ctx* c, void* p) try {
+    if (!c) return RT_E_INVALID;
+    c->err.clear();
+    auto it = std::find(c->host_blocks.begin(), c->host_blocks.end(), p);
+    if (!p || it == c->host_blocks.end()) return fail(c, RT_E_INVALID, "host_free: not a block of rt_host_alloc");
+    for (Replica& r : c->reps) { RT_HIP(c, hipSetDevice(r.device)); RT_HIP(c, hipDeviceSynchronize()); }   // no copy still uses it
+    c->host_blocks.erase(it);
+    RT_HIP(c, hipHostFree(p));
+    return RT_OK;
+} RT_ABI_CATCH(c)
+
+int rt_trace(rt_ctx* c, const rt_ray* host_rays, uint64_t n, rt_hit* host_out) try {
     return trace_host(c, host_rays, n, host_out, false);
-}
-int rt_occluded(rt_ctx* c, const rt_ray* host_rays, uint64_t n, uint8_t* host_out) {
+} RT_ABI_CATCH(c)
+int rt_occluded(rt_ctx* c, const rt_ray* host_rays, uint64_t n, uint8_t* host_out) try {
     return trace_host(c, host_rays, n, host_out, true);
-}
+} RT_ABI_CATCH(c)
 
 }  // extern "C"

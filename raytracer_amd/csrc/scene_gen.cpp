@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -81,10 +82,13 @@ void parallel_ranges(uint64_t n, F fn) {
     const unsigned nt = n < (1u << 16) ? 1u : hw;
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;
+    try { th.reserve(nt); } catch (...) { fn(0, n); return; }          // emplace_back below then never allocates
     const uint64_t per = (n + nt - 1) / nt;
     for (unsigned t = 0; t < nt; ++t) {
         const uint64_t b = std::min<uint64_t>(per * t, n), e = std::min<uint64_t>(b + per, n);
-        if (b < e) th.emplace_back([=] { fn(b, e); });
+        if (b >= e) continue;
+        // fn only writes caller-owned memory and cannot throw; a thread that cannot be started runs inline
+        try { th.emplace_back([=] { fn(b, e); }); } catch (...) { fn(b, e); }
     }
     for (auto& x : th) x.join();
 }
@@ -125,7 +129,7 @@ uint32_t rt_gen_cornell_spheres(void* out, uint32_t cap) {
 // (stacks+1) x (slices+1) grid, stack angle from +pi/2 down, two triangles per quad
 // (v[i][j], v[i+1][j], v[i+1][j+1]) and (v[i][j], v[i+1][j+1], v[i][j+1]), normals = normalize(v - c).
 uint32_t rt_gen_sphere_geometry(const float center[3], float radius, uint32_t stacks, uint32_t slices,
-                                const float material12[12], void* out, uint32_t cap) {
+                                const float material12[12], void* out, uint32_t cap) try {
     const uint64_t total64 = 2ull * stacks * slices;
     if (total64 > 0xFFFFFFFFull) return 0;
     const uint32_t total = (uint32_t)total64;
@@ -165,6 +169,8 @@ uint32_t rt_gen_sphere_geometry(const float center[3], float radius, uint32_t st
         }
     }
     return total;
+} catch (...) {
+    return 0;            // out of host memory for the vertex grid: nothing written (a real count is never 0 here)
 }
 
 // centre uniform in [0,1)^3, vertices = centre + uniform in [-h, h)^3.

@@ -78,9 +78,9 @@ def gather_rows(local, plan, index=None, group=None):
     """local: [padded_rows, row_elems...] tensor of this rank -> [h, row_elems...] on every rank."""
     if local.shape[0] != plan.padded_rows:
         raise ValueError(f"local buffer has {local.shape[0]} rows, plan needs {plan.padded_rows}")
-    if plan.world == 1:
+    if plan.world == 1 and not _group_up():
         full = local
-    else:
+    else:                                   # a process group of one rank still goes through the collective
         full = torch.empty((plan.world * plan.padded_rows,) + tuple(local.shape[1:]), dtype=local.dtype,
                            device=local.device)
         dist.all_gather_into_tensor(full, local.contiguous(), group=group)
@@ -89,13 +89,17 @@ def gather_rows(local, plan, index=None, group=None):
     return full.index_select(0, index)
 
 
+def _group_up():
+    return dist.is_available() and dist.is_initialized()
+
+
 def gather_rows_to(local, plan, dst=0, index=None, group=None):
     """Like gather_rows, but only rank `dst` receives the frame ([h, row_elems...]; None elsewhere): every other rank
     sends its stripes once, over its own direct xGMI link to dst, instead of the N-1 hops of a ring all-gather.
     This is the exchange the reference's presentation needs -- one process shows the frame."""
     if local.shape[0] != plan.padded_rows:
         raise ValueError(f"local buffer has {local.shape[0]} rows, plan needs {plan.padded_rows}")
-    if plan.world == 1:
+    if plan.world == 1 and not _group_up():
         full = local
     else:
         local = local.contiguous()
@@ -121,7 +125,7 @@ def shard_range(n, world, rank):
 
 def gather_ranges(local, n, world, group=None):
     """local: [per, ...] (padded) -> [n, ...] in ray order on every rank."""
-    if world == 1:
+    if world == 1 and not _group_up():
         return local[:n]
     full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(full, local.contiguous(), group=group)

@@ -161,3 +161,46 @@ def random_rays(n, first=0, seed=0x5EED0002):
     rays = np.zeros(n, dtype=RAY)
     lib().rt_gen_random_rays(seed, first, n, _ptr(rays))
     return rays
+
+
+# ---- adversarial geometry for the tie / epsilon / far-origin parity tests (scripts/fuzz_ties.py, tests/) ----------
+def tri_array(p0, p1, p2):
+    """TRIANGLE records from three (n, 3) vertex arrays, normal +z, grey."""
+    t = np.zeros(len(p0), dtype=TRIANGLE)
+    for name, p in (("v0", p0), ("v1", p1), ("v2", p2)):
+        t[name]["position"] = np.asarray(p, dtype=np.float32)
+        t[name]["normal"] = (0, 0, 1)
+    t["material"]["albedo"] = 0.7
+    return t
+
+
+def grid_scene(n, jitter_z, rng):
+    """n x n quads over the unit square in the plane z = f(x, y) (jitter_z = 0: exactly coplanar), two triangles each,
+    shared edges and vertices.  Returns (triangles, vertices)."""
+    xs = np.linspace(0, 1, n + 1, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    Z = (rng.standard_normal(X.shape) * jitter_z).astype(np.float32)
+    P = np.stack([X, Y, Z], -1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = tri_array(a.reshape(-1, 3), b.reshape(-1, 3), c.reshape(-1, 3))
+    t2 = tri_array(a.reshape(-1, 3), c.reshape(-1, 3), d.reshape(-1, 3))
+    return cat([t1, t2]), P.reshape(-1, 3)
+
+
+def rays_at(points, origins, tmin=0.0, tmax=1e20):
+    """Rays from `origins` through `points` (direction normalised in float64, then rounded to fp32)."""
+    points, origins = np.asarray(points, dtype=np.float64), np.asarray(origins, dtype=np.float64)
+    d = points - origins
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros(len(points), dtype=RAY)
+    r["o"], r["d"], r["tmin"], r["tmax"] = origins.astype(np.float32), d.astype(np.float32), tmin, tmax
+    return r
+
+
+def translated(tris, offset):
+    """Copy of `tris` with every position moved by `offset` (rounded to fp32: the scene IS the rounded numbers)."""
+    t = tris.copy()
+    off = np.asarray(offset, dtype=np.float32)
+    for v in ("v0", "v1", "v2"):
+        t[v]["position"] = (t[v]["position"].astype(np.float32) + off).astype(np.float32)
+    return t

@@ -13,31 +13,10 @@ from raytracer_amd import scenes
 rng = np.random.default_rng(12345)
 total_rays = total_bad = total_oracle = total_oracle_bad = 0
 
-def tri_array(p0, p1, p2):
-    t = np.zeros(len(p0), dtype=rt.TRIANGLE)
-    for name, p in (("v0", p0), ("v1", p1), ("v2", p2)):
-        t[name]["position"] = p.astype(np.float32)
-        t[name]["normal"] = (0, 0, 1)
-    t["material"]["albedo"] = 0.7
-    return t
-
+tri_array = scenes.tri_array
+rays_at = scenes.rays_at
 def grid_scene(n, jitter_z):
-    """n x n quads in the plane z = f(x, y) (jitter_z = 0: exactly coplanar), two triangles each, shared edges."""
-    xs = np.linspace(0, 1, n + 1, dtype=np.float32)
-    X, Y = np.meshgrid(xs, xs, indexing="ij")
-    Z = (rng.standard_normal(X.shape) * jitter_z).astype(np.float32)
-    P = np.stack([X, Y, Z], -1)
-    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
-    t1 = tri_array(a.reshape(-1, 3), b.reshape(-1, 3), c.reshape(-1, 3))
-    t2 = tri_array(a.reshape(-1, 3), c.reshape(-1, 3), d.reshape(-1, 3))
-    return scenes.cat([t1, t2]), P.reshape(-1, 3)
-
-def rays_at(points, origins):
-    d = points - origins
-    d = d / np.linalg.norm(d, axis=1, keepdims=True)
-    r = np.zeros(len(points), dtype=rt.RAY)
-    r["o"], r["d"], r["tmin"], r["tmax"] = origins.astype(np.float32), d.astype(np.float32), 0.0, 1e20
-    return r
+    return scenes.grid_scene(n, jitter_z, rng)
 
 def check(name, tris, rays, sph=None):
     global total_rays, total_bad, total_oracle, total_oracle_bad

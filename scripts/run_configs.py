@@ -137,11 +137,17 @@ def c4(n_tris, n_rays):
             res[name] = {"ms": round(ms, 3), "Mrays_s": round(n_rays / ms / 1e3, 1),
                          "same_as_bvh2": bool(hits.cpu().numpy().view(rt.HIT).tobytes() == keep["bvh2"].tobytes())}
         r.set_option(rt.OPT_RAY_BINNING, 2)
-        mh = min(n_rays, 1 << 24)
-        t = time.time(); hh = r.trace(rays_np[:mh]); dt = time.time() - t
-        res["host_ptr"] = {"rays": mh, "seconds": round(dt, 3), "host_ptr_Mrays_s": round(mh / dt / 1e6, 1),
-                           "same": bool(hh.tobytes() == keep["bvh2"][:mh].tobytes()),
-                           "note": "rt_trace: pageable H2D of rays + kernels + D2H of hits, 4 Mi-ray pieces"}
+        mh = min(n_rays, 1 << 25)
+        hp = {"rays": mh, "note": "rt_trace: host rays in + kernels + host hits out, 2 Mi-ray pieces on two streams; pinned = rt_host_alloc "
+                                  "blocks (DMA direct), pageable = staged through pinned buffers by host threads"}
+        p_rays, p_hits = r.host_alloc(mh, rt.RAY), r.host_alloc(mh, rt.HIT)
+        p_rays[:] = rays_np[:mh]
+        for name, src, dst in (("pinned", p_rays, p_hits), ("pageable", rays_np[:mh], np.empty(mh, dtype=rt.HIT))):
+            r.trace(src[: 1 << 22], out=dst[: 1 << 22])                  # warm: staging buffers
+            t = time.time(); hh = r.trace(src, out=dst); dt = time.time() - t
+            hp[name + "_seconds"] = round(dt, 4); hp[name + "_Mrays_s"] = round(mh / dt / 1e6, 1)
+            hp[name + "_same"] = bool(hh.tobytes() == keep["bvh2"][:mh].tobytes())
+        res["host_ptr"] = hp
     m = len(keep["brute"])
     res["gpu_brute_check"]["prim_id_mismatches_bvh4q"] = int((keep["brute"]["prim"] != keep["bvh4q"][:m]["prim"]).sum())
     res["layouts_agree"] = bool(keep["bvh2"].tobytes() == keep["bvh4q"].tobytes())
@@ -156,32 +162,57 @@ def c5(n_tris):
     e = tris["material"]["emission"]; e[::50] = (1.0, 0.9, 0.8); tris["material"]["emissionStrength"][::50] = 2.0   # 2 % emitters
     cam = rt.camera_look_at((0.5, 2.2, 0.5), (0.5, 0.5, 0.5), 45.0, w / h)
     n = w * h * spp
+    K = 1 << 15                                                          # rays per generation in the parity sample
+    idx = torch.from_numpy(np.sort(np.random.default_rng(5).choice(n, K, replace=False))).to(dev)
     with rt.Renderer((0,)) as r:
         r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
         r.create_data(tris); r.update_camera(cam)
         ra, rb, hits, thr, rad = f32(n * 8), f32(n * 8), f32(n * 4), f32(n * 4), f32(n * 4)
         fb = torch.empty(w * h, dtype=torch.int32, device=dev)
-        live = []
+        live, sample = [], []
 
-        def frame(count=False):
+        def frame(count=False, capture=False):
             a, b = ra, rb
-            r.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, a, spp=spp, seed=1, jitter=True, shade_seed=2)
+            if capture:                                                  # keep the primary rays / hits too (optional outputs)
+                pr, ph = f32(n * 8), f32(n * 4)
+                r.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, a, spp=spp, seed=1, jitter=True, shade_seed=2, rays=pr, hits=ph)
+                sample.append((pr.view(-1, 8)[idx].clone(), ph.view(-1, 4)[idx].clone()))
+                del pr, ph
+            else:
+                r.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, a, spp=spp, seed=1, jitter=True, shade_seed=2)
             if count:
                 live.append(n)
             for k in range(1, bounces):
                 if count:
                     live.append(int((a.view(-1, 8)[:, 7] > 0).sum()))
                 r.trace_dev(a, n, hits)
+                if capture:
+                    sample.append((a.view(-1, 8)[idx].clone(), hits.view(-1, 4)[idx].clone()))
                 if k + 1 == bounces:
                     r.shade_resolve_dev(a, hits, n, spp, thr, rad, None, fb)
                 else:
                     r.shade_dev(a, hits, n, thr, rad, b, key0=0, seed=2 + k)
                     a, b = b, a
-        frame(True); torch.cuda.synchronize()
+        frame(True, True); torch.cuda.synchronize()
         ms = timeit(frame, 2)
         traced = sum(live)
         res.update({"frame_ms": round(ms, 2), "closest_hit_rays": traced, "Mrays_s": round(traced / ms / 1e3, 1),
                     "live_rays_per_segment": live, "nonblack_pixels": int((fb.cpu().numpy() & 0xFFFFFF != 0).sum())})
+        # parity gate: a seeded sample of every ray generation (primary + each bounce) against the reference loop run as
+        # the brute-force HIP kernel over all triangles, and a sub-sample against the CPU oracle
+        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BRUTE)
+        gate = {"sample_rays_per_generation": K, "generations": len(sample), "prim_id_mismatches_vs_gpu_brute": 0, "bit_exact_vs_gpu_brute": True,
+                "oracle_sample_per_generation": 512, "prim_id_mismatches_vs_oracle": 0}
+        sc = oracle.Scene(tris)
+        for s_rays, s_hits in sample:
+            bh = f32(K * 4)
+            r.trace_dev(s_rays.contiguous().view(-1), K, bh); torch.cuda.synchronize()
+            got, ref = s_hits.cpu().numpy().view(rt.HIT).ravel(), bh.cpu().numpy().view(rt.HIT).ravel()
+            gate["prim_id_mismatches_vs_gpu_brute"] += int((got["prim"] != ref["prim"]).sum())
+            gate["bit_exact_vs_gpu_brute"] = bool(gate["bit_exact_vs_gpu_brute"] and got.tobytes() == ref.tobytes())
+            o = oracle.trace(sc, s_rays.cpu().numpy().view(rt.RAY).ravel()[:512])
+            gate["prim_id_mismatches_vs_oracle"] += int((o["prim"] != got["prim"][:512]).sum())
+        res["parity"] = gate
     out(res)
 
 

@@ -1,5 +1,6 @@
-// Host-code sanitizer driver (ASan + UBSan, CPU only): exercises the BVH builder / flatteners, the scene generators and
-// the OBJ reader on ordinary and degenerate inputs.  Built and run by tests/test_host_sanitizers.py.
+// Host-code sanitizer driver (ASan + UBSan, CPU only): exercises the BVH builder / flatteners, the host half of the scene
+// upload, the scene generators and the OBJ reader on ordinary and degenerate inputs and under injected allocation failures.  Built and run by tests/test_host_sanitizers.py.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,27 @@
 #include "../../raytracer_amd/host/rt_types.hpp"
 
 using namespace rt;
+
+// ---- allocation-failure injection --------------------------------------------------------------------------------
+// Every operator new of the process goes through here.  When armed, the g_countdown-th allocation from now (or any
+// allocation of at least g_big bytes) throws std::bad_alloc, the way a host out of memory would.  The extern "C" entry
+// points must turn that into RT_E_NOMEM (the header: "nothing is thrown across the ABI") without leaking or crashing.
+static std::atomic<long> g_countdown{ -1 };
+static std::atomic<size_t> g_big{ 0 };
+static void* injected_alloc(std::size_t n) {
+    const size_t big = g_big.load(std::memory_order_relaxed);
+    if (big && n >= big) throw std::bad_alloc();
+    if (g_countdown.load(std::memory_order_relaxed) >= 0 && g_countdown.fetch_sub(1) == 0) throw std::bad_alloc();
+    void* p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void* operator new(std::size_t n) { return injected_alloc(n); }
+void* operator new[](std::size_t n) { return injected_alloc(n); }
+void operator delete(void* p) noexcept { std::free(p); }
+void operator delete[](void* p) noexcept { std::free(p); }
+void operator delete(void* p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void* p, std::size_t) noexcept { std::free(p); }
 
 static int fails = 0;
 #define EXPECT(c) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
@@ -92,6 +114,50 @@ int main(int argc, char** argv) {
         }
         EXPECT(rt_load_obj((dir + "/missing.obj").c_str(), nullptr, nullptr, 0, &n) == RT_E_INVALID);
         EXPECT(rt_load_obj(nullptr, nullptr, nullptr, 0, &n) == RT_E_INVALID);
+    }
+    // allocation failures inside the entry points: every k-th allocation in turn, then "any large block"
+    {
+        const uint32_t n = 80000;                      // large enough for the multi-threaded builder (thread start, queue growth)
+        std::vector<Triangle> t(n);
+        EXPECT(rt_gen_soup(0x5EED0001ull, n, 0.02f, t.data(), n) == n);
+        rt_scene_stats st;
+        std::vector<uint32_t> nodes((size_t)n * 16), order(n);
+        int nomem = 0, ok = 0;
+        for (long k = 0; k < 400; ++k) {
+            g_countdown.store(k);
+            const int rc = rt_bvh_build_host(t.data(), n, sizeof(Triangle), 2 + (int)(k & 1), 4, 15, 1 + (int)(k % 3) * 2, &st,
+                                             nodes.data(), nodes.size(), order.data());
+            g_countdown.store(-1);
+            EXPECT(rc == RT_OK || rc == RT_E_NOMEM);
+            if (rc == RT_E_NOMEM) ++nomem; else if (rc == RT_OK) ++ok;
+            if (rc == RT_OK && k > 64) break;          // the build needs fewer allocations than k: nothing left to fail
+        }
+        EXPECT(nomem > 8 && ok > 0);
+        const float ctr[3] = { 0, 0, 0 }, mat[12] = { 0 };
+        std::vector<Triangle> g(2 * 200 * 200);
+        g_big.store(64 * 1024);                        // every large vector fails
+        EXPECT(rt_bvh_build_host(t.data(), n, sizeof(Triangle), 3, 4, 15, 2, &st, nullptr, 0, nullptr) == RT_E_NOMEM);
+        EXPECT(rt_gen_sphere_geometry(ctr, 1.f, 200, 200, mat, g.data(), (uint32_t)g.size()) == 0);      // documented: 0 = out of memory
+        g_big.store(0);
+        EXPECT(rt_gen_sphere_geometry(ctr, 1.f, 200, 200, mat, g.data(), (uint32_t)g.size()) == g.size());
+        EXPECT(rt_bvh_build_host(t.data(), n, sizeof(Triangle), 3, 4, 15, 2, &st, nullptr, 0, nullptr) == RT_OK);
+        if (argc > 1) {
+            const std::string p = std::string(argv[1]) + "/alloc.obj";
+            FILE* f = std::fopen(p.c_str(), "wb");
+            for (int i = 0; i < 3000; ++i) std::fprintf(f, "v %d 0 0\nv %d 1 0\nv %d 0 1\nf -3 -2 -1\n", i, i, i);
+            std::fclose(f);
+            uint64_t cnt = 0;
+            int seen_nomem = 0;
+            for (long k = 0; k < 40; ++k) {
+                g_countdown.store(k);
+                const int rc = rt_load_obj(p.c_str(), nullptr, nullptr, 0, &cnt);
+                g_countdown.store(-1);
+                EXPECT(rc == RT_OK || rc == RT_E_NOMEM);
+                seen_nomem += rc == RT_E_NOMEM;
+                if (rc == RT_OK) { EXPECT(cnt == 3000); break; }
+            }
+            EXPECT(seen_nomem > 0);
+        }
     }
     std::printf("host sanitizer driver: %d failures\n", fails);
     return fails ? 1 : 0;

@@ -43,3 +43,38 @@ def test_roofline_and_cpu_baseline_objects():
     # correctness gates ride beside the throughput number (north_star: mismatch rate stated)
     assert d["parity"]["prim_id_mismatches"] == 0 and d["parity"]["hit_records_bit_exact"] is True
     assert d["parity"]["bvh_walk_prim_id_mismatches"] == 0
+
+
+def test_self_launch_logic():
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a child process,
+    before the GPU is touched); under a launcher (WORLD_SIZE set) or with one GPU it runs in-process."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    a2 = bench.parse_args(["--gpus", "2", "--steps", "5", "--warmup", "1"])
+    assert bench.needs_self_launch(a2, {}) is True
+    assert bench.needs_self_launch(a2, {"WORLD_SIZE": "2", "RANK": "0"}) is False
+    assert bench.needs_self_launch(bench.parse_args([]), {}) is False
+    cmd = bench.launcher_command(a2, ["--gpus", "2", "--steps", "5", "--warmup", "1"], 29517)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "2", "--steps", "5", "--warmup", "1"]          # the ranks see the same flags
+    # the decision is taken before torch / the library are imported in bench.py
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("sys.exit(self_launch(") < src.index("import torch")
+
+
+def test_self_launch_propagates_the_exit_code(tmp_path, monkeypatch):
+    """A rank that fails makes the self-launched bench fail (rc != 0), nothing is swallowed."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    bad = tmp_path / "rank.py"
+    bad.write_text("import os, sys\nsys.exit(3 if os.environ.get('RANK') == '1' else 0)\n")
+    monkeypatch.setattr(bench, "launcher_command",
+                        lambda args, argv, port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                                  "--master-addr", "127.0.0.1", "--master-port", str(port), str(bad)])
+    assert bench.self_launch(bench.parse_args(["--gpus", "2"]), []) != 0
+    bad.write_text("print('ok')\n")
+    assert bench.self_launch(bench.parse_args(["--gpus", "2"]), []) == 0

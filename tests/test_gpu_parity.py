@@ -665,3 +665,232 @@ def test_adversarial_ties_and_epsilon_cases():
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_ties.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 differing records (rate 0.00e+00)" in p.stdout
+
+
+def test_far_origins_and_offset_scenes_lose_no_hits():
+    """scripts/far_origin.py: rays that start 10^2 .. 10^5 scene extents away, aimed at vertices, edge midpoints and the
+    box-edge-touching wall edges of the Cornell box and of coplanar / jittered grids, and the same scenes translated by
+    10^3 and 10^4.  The slab test's rounding grows with the ORIGIN's magnitude, the upload-time box pad only knows the
+    vertices'; the per-ray pad (kernels.hip make_slab) closes that: every BVH layout x kernel (ray-buffer strip kernel,
+    one-ray-per-lane kernel, tile kernel) must return the brute-force kernel's records bit for bit, and that kernel the
+    oracle's (frag.glsl:265-301: every triangle is tested; a BVH may not cull one the loop accepts)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("far_origin", os.path.join(root, "scripts", "far_origin.py"))
+    far = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(far)
+    tot = far.run(pad_on=True, verbose=False)
+    assert tot["rays"] > 1_000_000 and tot["tile_rays"] > 100_000
+    assert tot["bad"] == 0, f"ray-buffer kernels: {tot['bad']} of {tot['rays']} records differ from the reference loop"
+    assert tot["tile_bad"] == 0, f"tile kernel: {tot['tile_bad']} of {tot['tile_rays']} records differ from the reference loop"
+    assert tot["oracle_bad"] == 0, f"brute-force kernel vs oracle: {tot['oracle_bad']} of {tot['oracle']}"
+
+
+# ---- the paths the big configs (C4, C5) take automatically ---------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_soup():
+    """1.5 M random triangles: nodes + triangles exceed 48 MB (auto ray binning) and the tree's SAH cost exceeds 250
+    (auto primary-via-ray-buffer); its 4-wide stack bound exceeds the 20 LDS entries (capped stack with spill)."""
+    return scenes.soup(1_500_000, half_extent=0.008)
+
+
+def test_big_soup_takes_the_auto_paths_and_matches_the_reference_loop(big_soup, torch_dev):
+    torch = torch_dev
+    tris = big_soup
+    n = (1 << 20) + 12345
+    rays = scenes.random_rays(n)
+    rays["tmax"][::97] = 0.0                                    # some dead rays (their own bin)
+    hstats, _, _ = rt.bvh_build_host(tris, layout=rt.TRAVERSAL_BVH4Q, want_nodes=False)
+    with rt.Renderer((0,)) as r:                                # no options: everything below is what "auto" picks
+        st = r.create_data(tris)
+        assert st["n_nodes"] * 64 + st["n_tris"] * 48 > 48 << 20, "scene too small to trigger auto ray binning"
+        assert st["sah_cost"] > 250.0, "tree too coherent to trigger the ray-buffer primary path"
+        assert hstats["n_lights"] + 2 > 20, "stack bound too small to trigger the capped LDS stack"
+        d_rays = to_dev(torch, rays)
+        hits, occ = dev_buf(torch, n, 16), torch.zeros(n, dtype=torch.uint8, device="cuda")
+        r.trace_dev(d_rays, n, hits)
+        r.occluded_dev(d_rays, n, occ)
+        torch.cuda.synchronize()
+        got, got_occ = to_np(hits, rt.HIT).copy(), occ.cpu().numpy().copy()
+        assert (got["prim"][::97] == rt.MISS).all() and 0.05 < (got["prim"] != rt.MISS).mean() < 0.999
+        # (a) no binning, no capped stack, BVH2 nodes: every scheduling / layout choice gives the same records
+        r.set_option(rt.OPT_RAY_BINNING, 0)
+        r.set_option(rt.OPT_LDS_STACK, 0)
+        h2 = dev_buf(torch, n, 16)
+        r.trace_dev(d_rays, n, h2)
+        torch.cuda.synchronize()
+        assert to_np(h2, rt.HIT).tobytes() == got.tobytes(), "auto (binned, capped stack) vs plain strip kernel"
+        r.set_option(rt.OPT_RAY_BINNING, 2)
+        r.set_option(rt.OPT_LDS_STACK, 20)
+        # (b) the reference loop on the GPU over a 64 k sample, the CPU oracle over 2 k
+        idx = np.sort(np.random.default_rng(11).choice(n, 1 << 16, replace=False))
+        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BRUTE)
+        d_s = to_dev(torch, rays[idx])
+        hb, ob = dev_buf(torch, len(idx), 16), torch.zeros(len(idx), dtype=torch.uint8, device="cuda")
+        r.trace_dev(d_s, len(idx), hb)
+        r.occluded_dev(d_s, len(idx), ob)
+        torch.cuda.synchronize()
+        assert_parity(got[idx], to_np(hb, rt.HIT), "1.5 M soup: auto path vs brute-force kernel (64 k sample)")
+        assert np.array_equal(got_occ[idx], ob.cpu().numpy())
+        assert np.array_equal(got_occ, (got["prim"] != rt.MISS).astype(np.uint8))
+        sub = idx[:: len(idx) // 2048][:2048]
+        assert_parity(got[sub], oracle.trace(oracle.Scene(tris), rays[sub]), "1.5 M soup: auto path vs oracle (2 k sample)")
+        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_AUTO)
+        # (c) primary rays: auto = ray generation + ray-buffer kernel with library scratch; 1 = tile kernel
+        cam = rt.camera_look_at((0.5, 2.2, 0.5), (0.5, 0.5, 0.5), 45.0, 256 / 192)
+        r.update_camera(cam)
+        w, h, spp = 256, 192, 4
+        m = w * h * spp
+        out = {}
+        for path in (0, 1):
+            r.set_option(rt.OPT_PRIMARY, path)
+            ph, pr = dev_buf(torch, m, 16), dev_buf(torch, m, 32)
+            r.trace_primary_dev(w, h, ph, None if path == 0 else pr, spp=spp, seed=3, jitter=True)
+            torch.cuda.synchronize()
+            out[path] = to_np(ph, rt.HIT).copy()
+        assert out[0].tobytes() == out[1].tobytes(), "primary rays: ray-buffer path vs tile kernel"
+        o_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=3, jitter=True)
+        pidx = np.sort(np.random.default_rng(12).choice(m, 1024, replace=False))
+        assert_parity(out[0][pidx], oracle.trace(oracle.Scene(tris), o_rays[pidx]), "1.5 M soup: primary sample vs oracle")
+
+
+def test_c5_shaped_path_traced_frame_stage_by_stage():
+    """C5's workload in small: a soup (SAH cost > 250, so segment 0 takes the ray-buffer path on its own) with emitters, a
+    pinhole camera from rt_camera_look_at, 16 spp, 3 bounces, through the fused entry points C5 uses
+    (rt_primary_shade_stripes_dev, rt_trace_dev, rt_shade_dev, rt_shade_resolve_dev).  Every stage against orc_shade /
+    orc_resolve: bounce rays, throughput, radiance and the linear frame bit-exact, RGBA8 within 1 LSB."""
+    import torch
+    tris = scenes.soup(40_000, half_extent=0.04)             # SAH cost ~320
+    e = tris["material"]["emission"]; e[::50] = (1.0, 0.9, 0.8); tris["material"]["emissionStrength"][::50] = 2.0
+    w, h, spp, bounces, seed = 40, 24, 16, 3, 1
+    cam = rt.camera_look_at((0.5, 2.2, 0.5), (0.5, 0.5, 0.5), 45.0, w / h)
+    n = w * h * spp
+    f = lambda k: torch.empty(n * k, dtype=torch.float32, device="cuda")
+    sc = oracle.Scene(tris)
+    o_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=seed, jitter=True)
+    o_thr = np.ones((n, 4), dtype=np.float32); o_thr[:, 3] = 0
+    o_rad = np.zeros((n, 4), dtype=np.float32)
+    with rt.Renderer((0,)) as r:
+        st = r.create_data(tris)
+        assert st["sah_cost"] > 250.0
+        r.update_camera(cam)
+        ra, rb, hits, thr, rad = f(8), f(8), f(4), f(4), f(4)
+        lin = torch.empty(w * h * 4, dtype=torch.float32, device="cuda")
+        fb = torch.empty(w * h, dtype=torch.int32, device="cuda")
+        r.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, ra, spp=spp, seed=seed, jitter=True, shade_seed=seed + 1)
+        o_hits = oracle.trace(sc, o_rays)
+        o_rays = oracle.shade(sc, o_rays, o_hits, o_thr, o_rad, key0=0, seed=seed + 1)
+        for k in range(1, bounces):
+            torch.cuda.synchronize()
+            assert to_np(ra, rt.RAY).tobytes() == o_rays.tobytes(), f"segment {k}: rays differ"
+            assert thr.cpu().numpy().tobytes() == o_thr.tobytes(), f"segment {k}: throughput differs"
+            assert rad.cpu().numpy().tobytes() == o_rad.tobytes(), f"segment {k}: radiance differs"
+            r.trace_dev(ra, n, hits)
+            o_hits = oracle.trace(sc, o_rays)
+            torch.cuda.synchronize()
+            assert_parity(to_np(hits, rt.HIT), o_hits, f"segment {k} hits")
+            if k + 1 == bounces:
+                r.shade_resolve_dev(ra, hits, n, spp, thr, rad, lin, fb)
+                oracle.shade(sc, o_rays, o_hits, o_thr, o_rad, key0=0, seed=0)      # radiance only matters now (:313-338)
+            else:
+                r.shade_dev(ra, hits, n, thr, rad, rb, key0=0, seed=seed + 1 + k)
+                o_rays = oracle.shade(sc, o_rays, o_hits, o_thr, o_rad, key0=0, seed=seed + 1 + k)
+                ra, rb = rb, ra
+        torch.cuda.synchronize()
+        o_lin, o_rgba = oracle.resolve(o_rad, w * h, spp)
+        assert lin.cpu().numpy().tobytes() == o_lin.tobytes()
+        got = fb.cpu().numpy().view(np.uint8).reshape(-1, 4).astype(np.int32)
+        assert np.abs(got - o_rgba.astype(np.int32)).max() <= 1
+        assert (got[:, :3].sum(axis=1) > 0).mean() > 0.02           # emitters are seen
+
+
+def test_host_pointer_path_pipelined_and_pinned(torch_dev):
+    """rt_trace / rt_occluded stream the rays through pinned staging buffers in 2 Mi-ray pieces on two streams; a block
+    of rt_host_alloc (pinned) is read and written by DMA directly.  More than one ring of pieces, a ragged
+    tail, pageable and pinned buffers: all must give the device-resident entry point's records."""
+    torch = torch_dev
+    n = 7 * (1 << 20) + 77                                       # 4 pieces: ring of 3 wraps, last piece ragged
+    st_, rays = scenes.soup(20000, half_extent=0.02), scenes.random_rays(n)
+    rays["tmax"][::9] = 0.3
+    with rt.Renderer((0,)) as r:
+        r.create_data(st_)
+        d_rays, d_hits = to_dev(torch, rays), dev_buf(torch, n, 16)
+        d_occ = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        r.trace_dev(d_rays, n, d_hits)
+        r.occluded_dev(d_rays, n, d_occ)
+        torch.cuda.synchronize()
+        want, want_occ = to_np(d_hits, rt.HIT).tobytes(), d_occ.cpu().numpy().tobytes()
+        assert r.trace(rays).tobytes() == want                   # pageable in, pageable out
+        assert r.occluded(rays).tobytes() == want_occ
+        p_rays, p_out = r.host_alloc(n, rt.RAY), r.host_alloc(n, rt.HIT)      # pinned: DMA straight from / to them
+        p_rays[:] = rays
+        p_out[:] = 0
+        assert r.trace(p_rays, out=p_out) is p_out
+        assert p_out.tobytes() == want                           # pinned in, pinned out: no staging
+        assert r.trace(p_rays).tobytes() == want                 # pinned in, pageable out
+        out = np.zeros(n, dtype=rt.HIT)
+        assert r.trace(rays, out=out) is out and out.tobytes() == want
+        r.host_free(p_out)
+        with pytest.raises(RuntimeError, match="not a block"):
+            r.host_free(out)
+        assert r.trace(rays[:1000]).tobytes() == want[:16000]    # smaller than a piece, after a big call
+
+
+def test_launches_on_two_streams_share_scratch_safely(torch_dev):
+    """Per-slot scratch (cursor sets, spill columns, the binning permutation) is shared by launches; launches on different
+    streams are ordered by events inside the library, so un-synchronised use from two streams gives the right records."""
+    torch = torch_dev
+    n = 300_000
+    st_, rays = scenes.soup(60000, half_extent=0.02), scenes.random_rays(2 * n)
+    with rt.Renderer((0,)) as r:
+        r.set_option(rt.OPT_RAY_BINNING, 1)                      # both launches permute through the one binning buffer
+        r.create_data(st_)
+        d_a, d_b = to_dev(torch, rays[:n]), to_dev(torch, rays[n:])
+        h_ref_a, h_ref_b = dev_buf(torch, n, 16), dev_buf(torch, n, 16)
+        r.trace_dev(d_a, n, h_ref_a); r.trace_dev(d_b, n, h_ref_b)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = [(dev_buf(torch, n, 16), dev_buf(torch, n, 16)) for _ in range(6)]
+        for ha, hb in outs:                                     # 12 launches in flight on two streams, no host sync
+            r.trace_dev(d_a, n, ha, stream=s1)
+            r.trace_dev(d_b, n, hb, stream=s2)
+        torch.cuda.synchronize()
+        for ha, hb in outs:
+            assert torch.equal(ha.view(torch.int32), h_ref_a.view(torch.int32))
+            assert torch.equal(hb.view(torch.int32), h_ref_b.view(torch.int32))
+
+
+def test_rccl_collectives_on_gpu_tensors_world_1(tmp_path):
+    """The exchange step of raytracer_amd/dist.py on the "nccl" (= RCCL) backend with GPU tensors.  One GPU here, so a
+    group of one rank: gather_rows_to (dist.gather into views of the frame), gather_rows / gather_ranges
+    (all_gather_into_tensor) must run on the device and return the rank's own stripes in image order.  Own process: the
+    process group must not leak into the other tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+from raytracer_amd import dist as rd
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+for h, sh in ((37, 8), (64, 16)):
+    plan = rd.stripe_plan(h, 1, 0, sh)
+    local = torch.arange(plan.padded_rows * 5, dtype=torch.int32, device="cuda").view(plan.padded_rows, 5)
+    a = rd.gather_rows_to(local, plan, 0)
+    b = rd.gather_rows(local, plan)
+    assert a.is_cuda and b.is_cuda and a.shape == (h, 5)
+    assert torch.equal(a, local[:h]) and torch.equal(b, local[:h])
+r = torch.arange(1000, dtype=torch.float32, device="cuda").view(250, 4)
+assert torch.equal(rd.gather_ranges(r, 240, 1), r[:240])
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl world-1 ok")
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "rccl world-1 ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+

@@ -1,4 +1,6 @@
-"""Host code of the library (BVH builder and flatteners, scene generators, OBJ reader) under ASan + UBSan on the CPU.
+"""Host code of the library (BVH builder and flatteners, host half of the scene upload, scene generators, OBJ reader)
+under ASan + UBSan on the CPU, including injected allocation failures (every extern "C" entry point must return
+RT_E_NOMEM instead of letting std::bad_alloc cross the ABI).
 GPU sanitizers are not available on the pool; the kernels are covered by the parity tests instead."""
 import os
 import shutil
@@ -13,7 +15,7 @@ CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
 def test_host_sources_under_asan_ubsan(tmp_path):
     exe = tmp_path / "host_san"
-    srcs = [os.path.join(ROOT, "tests", "host_san", "driver.cpp")] + [os.path.join(CSRC, f) for f in ("bvh.cpp", "scene_gen.cpp", "obj_loader.cpp")]
+    srcs = [os.path.join(ROOT, "tests", "host_san", "driver.cpp")] + [os.path.join(CSRC, f) for f in ("bvh.cpp", "scene_host.cpp", "scene_gen.cpp", "obj_loader.cpp")]
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-fno-omit-frame-pointer", *srcs, "-o", str(exe), "-lpthread"]
     b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
