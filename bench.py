@@ -274,7 +274,8 @@ def main():
     }
 
     # ---- CPU baseline (oracle = reference semantics, brute force) + parity gate on the same sample --------
-    if not args.no_cpu_baseline and world == 1:       # the CPU legs run on rank 0 at N = 1 only
+    quick = os.environ.get("RT_BENCH_QUICK") == "1"   # kernel A/B runs: skip the CPU legs and the transfer figure
+    if not args.no_cpu_baseline and world == 1 and not quick:       # the CPU legs run on rank 0 at N = 1 only
         import oracle
         torch.cuda.synchronize()
         live = plan.local_stripes * STRIPE * W * SPP if world > 1 else W * H * SPP
@@ -320,7 +321,7 @@ def main():
     # ---- SURVEY 8(d) second figure: closest hit INCLUDING the transfers (host rays in, host hits out) ----------------
     # What the reference's frame loop would call with host arrays (rt_trace): 2 Mi-ray pieces, H2D | kernel | D2H
     # overlapped on two streams.  Never `value`.  The PCIe bound is 32 B in + 16 B out per ray over the measured link rates.
-    if world == 1:
+    if world == 1 and not quick:
         m = min(n_local, XFER_SAMPLE)
         h_rays = brays.view(-1, 8)[:m].cpu().numpy().view(rt.RAY).ravel()
         want = bhits.view(-1, 4)[:m].cpu().numpy().view(rt.HIT).ravel()

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libraytracer_amd.so")
+# RT_AMD_LIB: development hook -- another build of the same library (A/B of kernel variants on one GPU box,
+# scripts/ab_variants.sh).  Unset in every test, smoke() and the driver's bench run.
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "csrc", "libraytracer_amd.so")
 
 
 class rt_scene_stats(C.Structure):

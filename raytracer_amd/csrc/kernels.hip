@@ -385,8 +385,16 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 // next rays of the chunk (rank by mbcnt over the idle ballot: coalesced reads), while the other lanes keep their
 // traversal state, and a new chunk is drawn as soon as the current one is handed out, so the only tail is the
 // one at the end of the launch.  Each lane writes its hit when it finishes; results do not depend on the order.
+#ifndef RT_STRIP_WAVES
+#define RT_STRIP_WAVES 0          // waves per SIMD the register allocator is asked to make room for (0 = its own choice)
+#endif
+#if RT_STRIP_WAVES
+#define RT_STRIP_ATTR __attribute__((amdgpu_waves_per_eu(RT_STRIP_WAVES, 8)))
+#else
+#define RT_STRIP_ATTR
+#endif
 template <int MODE, bool ANY, bool COUNT, bool CAPPED>
-__global__ __launch_bounds__(kBlock) void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
+__global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
                                                         unsigned long long* __restrict__ work /* 8 chunk cursors + mask, kCursorStride apart, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
