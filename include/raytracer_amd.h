@@ -175,6 +175,15 @@ int  rt_trace_primary_stripes_dev(rt_ctx* ctx, int slot, uint32_t w, uint32_t h,
                                   rt_ray* d_rays_out, rt_hit* d_hits_out, void* stream);
 int  rt_trace_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits_out, void* stream);
 int  rt_occluded_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, uint64_t n, uint8_t* d_out, void* stream);
+/* rt_trace_dev that allocates nothing.  No counterpart in the reference: it is for callers that cannot call hipMalloc
+ * -- code under HIP graph capture, tight serving loops, harnesses that forbid it.  Same rays in, same hit records out
+ * (bit for bit) as rt_trace_dev, but the kernel's scratch (chunk cursors, spill columns of the traversal stack, the
+ * ray-binning permutation) is a static device array inside the library (about 36 MiB per GPU, held until the process
+ * ends) instead of per-context allocations, and the call performs no hipMalloc / hipFree.  n <= RT_NOALLOC_MAX_RAYS,
+ * else RT_E_TOO_LARGE (split the buffer).  Every call on one GPU shares that array: calls that overlap on one GPU --
+ * different streams, contexts or threads -- race; keep them stream-ordered.  RT_OPT_COUNTERS is ignored. */
+#define RT_NOALLOC_MAX_RAYS (1u << 22)
+int  rt_trace_dev_noalloc(rt_ctx* ctx, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits_out, void* stream);
 /* frag.glsl:321-330 for one light: from (rays, hits) build the shadow ray at p + N*0.001 towards
  * light_pos, trace closest-hit, d_lit[i] = 1 lit / 0 shadowed / 2 primary miss.
  * d_shadow_rays_out may be NULL. */

@@ -39,6 +39,7 @@ HIT = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("prim", "u4")])
 assert RAY.itemsize == 32 and HIT.itemsize == 16
 
 OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING, OPT_LDS_STACK, OPT_PRIMARY, OPT_RAY_PAD = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+NOALLOC_MAX_RAYS = 1 << 22
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
 TRAVERSAL_BVH = TRAVERSAL_BVH4Q
 
@@ -242,6 +243,10 @@ class Renderer:
 
     def trace_dev(self, rays, n, hits, slot=0, stream=None):
         self._check(self._lib.rt_trace_dev(self._ctx, slot, _ptr(rays), n, _ptr(hits), _stream_ptr(stream)))
+
+    def trace_dev_noalloc(self, rays, n, hits, slot=0, stream=None):
+        """rt_trace_dev_noalloc: same records as trace_dev, no device allocation (n <= NOALLOC_MAX_RAYS)."""
+        self._check(self._lib.rt_trace_dev_noalloc(self._ctx, slot, _ptr(rays), n, _ptr(hits), _stream_ptr(stream)))
 
     def occluded_dev(self, rays, n, out, slot=0, stream=None):
         self._check(self._lib.rt_occluded_dev(self._ctx, slot, _ptr(rays), n, _ptr(out), _stream_ptr(stream)))

@@ -48,6 +48,7 @@ SYMBOLS = [
     ("rt_trace_primary_dev", _I, [_P, _I, _U32, _U32, _U32, _U32, _U32, _U32, _I, _P, _P, _P]),
     ("rt_trace_primary_stripes_dev", _I, [_P, _I, _U32, _U32, _U32, _U32, _U32, _U32, _U32, _U32, _I, _P, _P, _P]),
     ("rt_trace_dev", _I, [_P, _I, _P, _U64, _P, _P]),
+    ("rt_trace_dev_noalloc", _I, [_P, _I, _P, _U64, _P, _P]),
     ("rt_occluded_dev", _I, [_P, _I, _P, _U64, _P, _P]),
     ("rt_shadow_dev", _I, [_P, _I, _P, _P, _U64, C.POINTER(C.c_float), _P, _P, _P]),
     ("rt_bounce_dev", _I, [_P, _I, _P, _P, _U64, _U32, _U32, _P, _P]),

@@ -1106,6 +1106,53 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
     return hipGetLastError();
 }
 
+// ---- allocation-free closest hit (rt_trace_dev_noalloc) -------------------------------------------------------
+// Callers that cannot call hipMalloc (code under graph capture, serving loops) get the strip kernel with its scratch
+// -- chunk cursors, spill columns of the capped stack, the binning permutation and histograms -- in this file-scope
+// device array instead of per-context allocations.  Every GPU the library runs on holds its own copy (kNoAllocBytes,
+// about 36 MiB) until the process ends.  `scratch` below is only a host-side stand-in for the symbol: host code uses
+// the per-device address that hipGetSymbolAddress returned (noalloc_init), never the name.
+constexpr size_t kNoAllocWorkBytes = 4096;                                                   // cursor set (kWorkWords u64), own lines
+constexpr size_t kNoAllocSpillWords = (size_t)kNoAllocSpillEntries * kNoAllocMaxBlocks * kThreads;
+constexpr size_t kNoAllocBinWords = (size_t)kNoAllocMaxRays + (size_t)kNoAllocBinBlocks * kBins + kBins + 4;
+constexpr size_t kNoAllocBytes = ((kNoAllocWorkBytes + (kNoAllocSpillWords + kNoAllocBinWords) * 4) + 255) / 256 * 256;
+static_assert(kWorkWords * sizeof(unsigned long long) <= kNoAllocWorkBytes, "cursor set does not fit its slice");
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
+size_t noalloc_bytes() { return kNoAllocBytes; }
+
+hipError_t noalloc_init(void** out) {                 // the device that is current; rt_create calls this once per slot
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    *out = p;
+    return hipSuccess;
+}
+
+hipError_t launch_trace_noalloc(void* d_scratch, const DevScene& s, int mode, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
+                                hipStream_t st, uint32_t strip, int refill, int lds_cap, bool bin, const BinGrid& grid, uint32_t min_run) {
+    if (n == 0) return hipSuccess;
+    if (!d_scratch || n > kNoAllocMaxRays) return hipErrorInvalidValue;
+    unsigned char* base = static_cast<unsigned char*>(d_scratch);
+    StripScratch sc;
+    sc.work = reinterpret_cast<unsigned long long*>(base);
+    sc.spill = reinterpret_cast<int*>(base + kNoAllocWorkBytes);
+    sc.max_blocks = kNoAllocMaxBlocks;
+    // the spill slice holds kNoAllocSpillEntries entries per thread: trees that are deeper keep more of the stack in LDS
+    const int need = (int)s.stack_depth + 2;
+    sc.lds_cap = std::max(lds_cap >= 2 ? lds_cap : need, need - (int)kNoAllocSpillEntries);
+    const uint32_t* perm = nullptr;
+    if (bin && mode != kBrute && strip >= 64) {
+        uint32_t* bw = reinterpret_cast<uint32_t*>(base + kNoAllocWorkBytes) + kNoAllocSpillWords;
+        hipError_t e = launch_bin(d_rays, n, grid, bw, min_run, st, kNoAllocBinBlocks);
+        if (e != hipSuccess) return e;
+        perm = bw;
+    }
+    return launch_trace(s, mode, false, false, d_rays, n, d_hits, nullptr, nullptr, st, strip, refill, perm,
+                        perm ? bin_flag(perm, n, kNoAllocBinBlocks) : nullptr, sc);
+}
+
 hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, bool count, uint32_t w, uint32_t h,
                           uint32_t y0, uint32_t rows, uint32_t stripe_h, uint32_t stripe_step, uint32_t spp,
                           uint32_t seed, int jitter, rt_ray* d_rays_out, rt_hit* d_hits,

@@ -59,6 +59,17 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
                         const uint32_t* d_perm /* order in which rays are handed out (strip kernel only) or null */,
                         const uint32_t* d_perm_on /* device flag: 0 = ignore d_perm */, const StripScratch& sc);
 
+// Allocation-free closest hit (rt_trace_dev_noalloc): the strip kernel with every scratch buffer in a static device
+// array of noalloc_bytes() bytes per GPU.  noalloc_init returns that array's address on the CURRENT device.
+constexpr uint64_t kNoAllocMaxRays = 1ull << 22;      // rays per call (the binning permutation is part of the array)
+constexpr uint32_t kNoAllocSpillEntries = 8;          // stack entries per thread that may spill; deeper trees use more LDS
+constexpr uint32_t kNoAllocMaxBlocks = 2048;          // persistent grid bound (8 blocks x 256 CUs)
+constexpr uint32_t kNoAllocBinBlocks = 256;           // histogram rows of the binning pass
+size_t noalloc_bytes();
+hipError_t noalloc_init(void** d_scratch_out);
+hipError_t launch_trace_noalloc(void* d_scratch, const DevScene& s, int mode, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
+                                hipStream_t st, uint32_t strip, int refill, int lds_cap, bool bin, const BinGrid& grid, uint32_t min_run);
+
 // Capped LDS stack of the strip kernel (kernels.hip "Capped stack"): entries beyond lds_cap spill to global memory,
 // one column per thread of the persistent grid (at most 8 blocks of kThreads per CU).
 constexpr int kThreads = 256;

@@ -129,6 +129,7 @@ struct Replica {
     // by its next user.  Any number of launches may therefore be in flight on any streams.
     hipEvent_t sc_ev[kNumScratchEvents] = {};
     bool sc_used[kNumScratchEvents] = {};
+    void* d_noalloc = nullptr;         // this device's copy of the static scratch array of rt_trace_dev_noalloc
     HostPipe pipe;
     std::string err;
 };
@@ -382,7 +383,8 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) try {
         r.device = d;
         bool ok = hipSetDevice(d) == hipSuccess && hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) == hipSuccess &&
                   hipMalloc(&r.d_counters, counter_words * sizeof(unsigned long long)) == hipSuccess &&
-                  hipMemset(r.d_counters, 0, counter_words * sizeof(unsigned long long)) == hipSuccess;
+                  hipMemset(r.d_counters, 0, counter_words * sizeof(unsigned long long)) == hipSuccess &&
+                  noalloc_init(&r.d_noalloc) == hipSuccess;          // this device's address of the static scratch array
         for (int k = 0; ok && k < kNumScratchEvents; ++k) ok = hipEventCreateWithFlags(&r.sc_ev[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) { rt_destroy(c.release()); return RT_E_DEVICE; }
     }
@@ -618,6 +620,22 @@ int rt_trace_dev(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* 
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
     RT_HIP(c, trace_rays(c, r, false, c->counters != 0, d_rays, n, d_hits, nullptr, st));
+    return RT_OK;
+} RT_ABI_CATCH(c)
+
+// rt_trace_dev for callers that cannot allocate: no hipMalloc / hipFree, no allocating library routine.  The strip
+// kernel's scratch is this device's copy of a static device array (kernels.hip, noalloc_bytes()); calls that overlap
+// on one GPU share it and race.
+int rt_trace_dev_noalloc(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits, void* stream) try {
+    int rc = check_stage(c, slot, false);
+    if (rc) return rc;
+    if (n && (!d_rays || !d_hits)) return fail(c, RT_E_INVALID, "trace_noalloc: null device pointer");
+    if (n > RT_NOALLOC_MAX_RAYS) return fail(c, RT_E_TOO_LARGE, "trace_noalloc: more than RT_NOALLOC_MAX_RAYS (4194304) rays in one call; split the buffer");
+    Replica& r = c->reps[slot];
+    RT_HIP(c, hipSetDevice(r.device));
+    const int mode = c->mode();
+    RT_HIP(c, launch_trace_noalloc(r.d_noalloc, c->dev_scene(r), mode, d_rays, n, d_hits, (hipStream_t)stream, c->strip, c->refill,
+                                   c->lds_stack, wants_binning(c, mode, n), c->bin_grid, c->binning == 1 ? 0u : kBinMinRun));
     return RT_OK;
 } RT_ABI_CATCH(c)
 
