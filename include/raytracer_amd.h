@@ -101,6 +101,12 @@ typedef struct {
     uint64_t wave_max_nodes;   /* sum over waves of the per-wave maximum of `nodes` (divergence probe) */
     uint64_t wave_max_tris;    /* same for triangle tests */
     uint64_t waves;
+    /* scheduling probes of the ray-buffer kernel (summed over scheduling rounds of all waves; for that kernel `waves` is
+       the number of rounds, wave_max_nodes / wave_max_tris the lanes that took an interior step / a triangle test) */
+    uint64_t idle_lane_rounds;     /* lanes without a ray, waiting for the next refill */
+    uint64_t blocked_lane_rounds;  /* lanes that hold a parked leaf and stand on a second one: cannot walk on */
+    uint64_t drained_lane_rounds;  /* lanes with an empty stack waiting for the triangle block */
+    uint64_t tri_rounds;           /* rounds in which the triangle block ran */
 } rt_counters;
 
 /* ---- life cycle --------------------------------------------------------------------------------

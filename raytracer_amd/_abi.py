@@ -24,7 +24,9 @@ class rt_scene_stats(C.Structure):
 class rt_counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("nodes", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64),
-                ("wave_max_nodes", C.c_uint64), ("wave_max_tris", C.c_uint64), ("waves", C.c_uint64)]
+                ("wave_max_nodes", C.c_uint64), ("wave_max_tris", C.c_uint64), ("waves", C.c_uint64),
+                ("idle_lane_rounds", C.c_uint64), ("blocked_lane_rounds", C.c_uint64), ("drained_lane_rounds", C.c_uint64),
+                ("tri_rounds", C.c_uint64)]
 
 
 # every symbol include/raytracer_amd.h declares: (name, restype, argtypes)

@@ -126,27 +126,28 @@ __device__ __forceinline__ float safe_rcp(float d) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Per-ray slab constants in register pairs, so that the two planes of one axis go through one v_pk_fma_f32:
-// t = plane * idir + (-o * idir).
+// Per-ray slab constants: t = plane * idir + (-o * idir).
 //
 // Per-ray pad.  The boxes are padded at build time by 2^-pad_log2 * max|vertex coordinate|, which covers rounding that
 // grows with the SCENE's magnitudes.  The slab arithmetic above and Moeller-Trumbore's s = o - v0 also work on numbers
 // of the ORIGIN's magnitude: the slab t is off by up to ~|o * idir| * 2^-23 (the two large terms cancel), and the
 // triangle test accepts rays that pass ~|o| * 2^-22 beside a triangle.  A ray that starts hundreds of scene extents away
 // would therefore lose leaves whose triangle the reference loop accepts.  So every ray widens every box by
-// m = ray_pad * max|o_a| (ray_pad = the same 2^-pad_log2) on its own: the entry t moves down and the exit t up by
-// m * |idir_a|, folded into the additive constants here -- the node step itself costs nothing more.
-// BVH4q pairs are (entry, exit); BVH2 pairs are (lo plane, hi plane), which move by -m / +m in space.
-struct Slab { v2f ix, iy, iz, ox, oy, oz; };
+// m = ray_pad * max|o_a| (ray_pad = the same 2^-pad_log2) on its own: the entry t of an axis moves down and the exit t up
+// by m * |idir_a|.  Kept as seven values (one more than without the pad, so the kernel still fits 72 VGPRs = 7 waves per
+// SIMD): idir, the ENTRY-side constants e_a = -o_a * idir_a - m * |idir_a|, and m2 = 2 m; the exit-side constant of an
+// axis is e_a + m2 * |idir_a|, one fma in the node step.  (BVH2 nodes hold (lo, hi) planes instead of (entry, exit):
+// there e_a = -o_a * idir_a - m * idir_a belongs to the lo plane and e_a + m2 * idir_a to the hi plane.)
+struct Slab { float ix, iy, iz, ex, ey, ez, m2; };
 template <int MODE>
 __device__ __forceinline__ Slab make_slab(f3 o, f3 d, float ray_pad) {
     const f3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    const f3 od = mk(-o.x * id.x, -o.y * id.y, -o.z * id.z);
     const float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) * ray_pad;
     const f3 w = MODE == kBvh4q ? mk(m * fabsf(id.x), m * fabsf(id.y), m * fabsf(id.z)) : mk(m * id.x, m * id.y, m * id.z);
     Slab s;
-    s.ix = (v2f){ id.x, id.x }; s.iy = (v2f){ id.y, id.y }; s.iz = (v2f){ id.z, id.z };
-    s.ox = (v2f){ od.x - w.x, od.x + w.x }; s.oy = (v2f){ od.y - w.y, od.y + w.y }; s.oz = (v2f){ od.z - w.z, od.z + w.z };
+    s.ix = id.x; s.iy = id.y; s.iz = id.z;
+    s.ex = -o.x * id.x - w.x; s.ey = -o.y * id.y - w.y; s.ez = -o.z * id.z - w.z;
+    s.m2 = m + m;
     return s;
 }
 
@@ -160,12 +161,16 @@ __device__ __forceinline__ int bvh2_step(const float4* __restrict__ nodes, int n
     const int popped = stk[(sp - 1) * kBlock];
     float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
     if (COUNT) { ++c.nodes; c.box += 2; }
-    v2f ax = __builtin_elementwise_fma((v2f){ q0.x, q0.y }, sl.ix, sl.ox);
-    v2f ay = __builtin_elementwise_fma((v2f){ q0.z, q0.w }, sl.iy, sl.oy);
-    v2f az = __builtin_elementwise_fma((v2f){ q2.x, q2.y }, sl.iz, sl.oz);
-    v2f bx = __builtin_elementwise_fma((v2f){ q1.x, q1.y }, sl.ix, sl.ox);
-    v2f by = __builtin_elementwise_fma((v2f){ q1.z, q1.w }, sl.iy, sl.oy);
-    v2f bz = __builtin_elementwise_fma((v2f){ q2.z, q2.w }, sl.iz, sl.oz);
+    // (lo, hi) plane constants of the three axes: lo plane moved out by -m, hi plane by +m (per-ray pad, make_slab)
+    const v2f ix2 = (v2f){ sl.ix, sl.ix }, iy2 = (v2f){ sl.iy, sl.iy }, iz2 = (v2f){ sl.iz, sl.iz };
+    const v2f ox2 = (v2f){ sl.ex, __fmaf_rn(sl.m2, sl.ix, sl.ex) }, oy2 = (v2f){ sl.ey, __fmaf_rn(sl.m2, sl.iy, sl.ey) },
+              oz2 = (v2f){ sl.ez, __fmaf_rn(sl.m2, sl.iz, sl.ez) };
+    v2f ax = __builtin_elementwise_fma((v2f){ q0.x, q0.y }, ix2, ox2);
+    v2f ay = __builtin_elementwise_fma((v2f){ q0.z, q0.w }, iy2, oy2);
+    v2f az = __builtin_elementwise_fma((v2f){ q2.x, q2.y }, iz2, oz2);
+    v2f bx = __builtin_elementwise_fma((v2f){ q1.x, q1.y }, ix2, ox2);
+    v2f by = __builtin_elementwise_fma((v2f){ q1.z, q1.w }, iy2, oy2);
+    v2f bz = __builtin_elementwise_fma((v2f){ q2.z, q2.w }, iz2, oz2);
     float tn0 = fmaxf(fmaxf(fminf(ax.x, ax.y), fminf(ay.x, ay.y)), fmaxf(fminf(az.x, az.y), tmin));
     float tf0 = fminf(fminf(fmaxf(ax.x, ax.y), fmaxf(ay.x, ay.y)), fminf(fmaxf(az.x, az.y), bt));
     float tn1 = fmaxf(fmaxf(fminf(bx.x, bx.y), fminf(by.x, by.y)), fmaxf(fminf(bz.x, bz.y), tmin));
@@ -194,17 +199,22 @@ __device__ __forceinline__ void cswap(uint32_t& ka, int& ra, uint32_t& kb, int& 
 // Capped stack of the ray-buffer kernel: the first `cap` entries (RT_OPT_LDS_STACK, default 20) of a lane's stack live in LDS, deeper ones in
 // a per-thread column of a global spill area.  The worst-case depth of a BVH4q (3 pushes per level) is far above
 // what rays use, and sizing LDS for the worst case holds the kernel at 3-4 waves per SIMD; with the cap it runs at 8.
-struct Spill { int* col; size_t stride; int cap; };   // this thread's column, stride = threads of the launch, LDS entries
+// base and stride are wave-uniform (SGPRs); the thread's column is recomputed where it is needed (the spill path is rare),
+// so that the capped stack costs no VGPRs in the traversal loop.
+struct Spill { int* base; uint32_t stride; int cap; };   // [entry][thread of the launch], stride = threads of the launch, LDS entries
+__device__ __forceinline__ int* spill_slot(const Spill& sp_, int idx) {
+    return sp_.base + ((size_t)(uint32_t)(idx - sp_.cap) * sp_.stride + blockIdx.x * (uint32_t)kBlock + threadIdx.x);
+}
 __device__ __forceinline__ int st_read(const int* __restrict__ stk, const Spill& sp_, int idx) {
-    return idx < sp_.cap ? stk[idx * kBlock] : sp_.col[(size_t)(idx - sp_.cap) * sp_.stride];
+    return idx < sp_.cap ? stk[idx * kBlock] : *spill_slot(sp_, idx);
 }
 __device__ __forceinline__ void st_write(int* __restrict__ stk, const Spill& sp_, int idx, int v) {
-    if (idx < sp_.cap) stk[idx * kBlock] = v; else sp_.col[(size_t)(idx - sp_.cap) * sp_.stride] = v;
+    if (idx < sp_.cap) stk[idx * kBlock] = v; else *spill_slot(sp_, idx) = v;
 }
 
 template <bool COUNT, bool CAPPED = false>
 __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
-                                          int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0, 0 }) {
+                                          int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0u, 0 }) {
     const uint4* np = reinterpret_cast<const uint4*>(nodes) + (size_t)node * 4;
     // this step touches stack slots sp-1 .. sp+2: all in LDS unless the lane is unusually deep
     const bool in_lds = !CAPPED || sp + 3 <= spill.cap;
@@ -214,16 +224,17 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     const uint2 q3 = *reinterpret_cast<const uint2*>(np + 3);
     const uint32_t w = q0.w;
     if (COUNT) { ++c.nodes; c.box += w >> 24; }
-    const float idx = sl.ix.x, idy = sl.iy.x, idz = sl.iz.x;
+    const float idx = sl.ix, idy = sl.iy, idz = sl.iz;
     const float sx = __uint_as_float((w << 23) & 0x7f800000u) * idx;
     const float sy = __uint_as_float((w << 15) & 0x7f800000u) * idy;
     const float sz = __uint_as_float((w << 7) & 0x7f800000u) * idz;
-    const float gx = __uint_as_float(q0.x), gy = __uint_as_float(q0.y), gz = __uint_as_float(q0.z);
     const v2f sx2 = (v2f){ sx, sx }, sy2 = (v2f){ sy, sy }, sz2 = (v2f){ sz, sz };
-    // (entry, exit) constants of the node: grid origin * idir + the ray's (-o * idir -/+ per-ray pad)
-    const v2f ax2 = __builtin_elementwise_fma((v2f){ gx, gx }, sl.ix, sl.ox);
-    const v2f ay2 = __builtin_elementwise_fma((v2f){ gy, gy }, sl.iy, sl.oy);
-    const v2f az2 = __builtin_elementwise_fma((v2f){ gz, gz }, sl.iz, sl.oz);
+    // (entry, exit) constants of the node: grid origin * idir + the ray's entry constant, the exit side 2 m |idir| later
+    const float aex = __fmaf_rn(__uint_as_float(q0.x), idx, sl.ex), aey = __fmaf_rn(__uint_as_float(q0.y), idy, sl.ey),
+                aez = __fmaf_rn(__uint_as_float(q0.z), idz, sl.ez);
+    const v2f ax2 = (v2f){ aex, __fmaf_rn(sl.m2, fabsf(idx), aex) };
+    const v2f ay2 = (v2f){ aey, __fmaf_rn(sl.m2, fabsf(idy), aey) };
+    const v2f az2 = (v2f){ aez, __fmaf_rn(sl.m2, fabsf(idz), aez) };
     // The ray's direction signs pick, once per node and for all four children, which plane word is the entry
     // side and which the exit side: no per-axis min/max later.  Empty slots are stored inverted (lo 255, hi 0),
     // so their entry lies behind their exit whatever the signs and they miss without a count check.
@@ -282,7 +293,7 @@ __device__ __forceinline__ void bvh2_leaf(const float4* __restrict__ tris, int n
 
 template <int MODE, bool COUNT, bool CAPPED = false>
 __device__ __forceinline__ int bvh_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
-                                        int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0, 0 }) {
+                                        int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0u, 0 }) {
     if (MODE == kBvh4q) return bvh4q_step<COUNT, CAPPED>(nodes, node, sl, tmin0, bt, stk, sp, c, spill);
     return bvh2_step<COUNT>(nodes, node, sl, tmin0, bt, stk, sp, c);
 }
@@ -385,8 +396,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 // next rays of the chunk (rank by mbcnt over the idle ballot: coalesced reads), while the other lanes keep their
 // traversal state, and a new chunk is drawn as soon as the current one is handed out, so the only tail is the
 // one at the end of the launch.  Each lane writes its hit when it finishes; results do not depend on the order.
+// Waves per SIMD the register allocator is asked to make room for (0 = its own choice).  Left alone it takes 80 VGPRs
+// (6 waves per SIMD); asked for 7 it fits the kernel into 72 without spilling (8 would need 64 and spills in the loop:
+// twice as slow).  One more wave per SIMD is worth 3-4 % on incoherent rays (profiles/r02f_ab.txt).
 #ifndef RT_STRIP_WAVES
-#define RT_STRIP_WAVES 0          // waves per SIMD the register allocator is asked to make room for (0 = its own choice)
+#define RT_STRIP_WAVES 7
 #endif
 #if RT_STRIP_WAVES
 #define RT_STRIP_ATTR __attribute__((amdgpu_waves_per_eu(RT_STRIP_WAVES, 8)))
@@ -412,7 +426,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
     const uint64_t n_chunks = (n + strip - 1) / strip;
     const uint32_t per_q = (uint32_t)((n_chunks + 7) / 8);            // chunks per eighth
     uint32_t q = blockIdx.x & 7u, q_done = 0;                         // workgroups go round-robin over the 8 XCDs
-    const Spill spill = { CAPPED ? spill_base + (size_t)blockIdx.x * kBlock + threadIdx.x : nullptr, (size_t)gridDim.x * kBlock, lds_cap };
+    const Spill spill = { CAPPED ? spill_base : nullptr, gridDim.x * (uint32_t)kBlock, lds_cap };
     stk[0] = kDone;
     int node = kDone, sp = 1;
     uint64_t my = 0;
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
     Counters c = { 0, 0, 0, 0 };
     uint32_t n_mine = 0;
     uint32_t w_rounds = 0, w_i = 0, w_t = 0;    // wave-uniform scheduling probes (COUNT builds)
+    uint32_t w_idle = 0, w_blocked = 0, w_pend = 0, w_tblocks = 0;
     int pend = 0;                               // postponed leaf (leaf refs are negative; 0 = none)
     for (;;) {
         const bool idle = node == kDone && pend == 0;
@@ -494,13 +509,14 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         // reaches a leaf parks it in `pend` and keeps walking from its stack; the triangle block is skipped
         // (wave-uniform branch) until at least `tth` lanes hold a parked leaf or no lane can walk any further.
         const bool need_i = node >= 0;
-        if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); }
+        if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); w_idle += __popcll(__ballot(node == kDone && pend == 0)); }
         if (need_i) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
         if (node < 0 && node != kDone && pend == 0) { pend = node; --sp; node = CAPPED ? st_read(stk, spill, sp) : stk[sp * kBlock]; }
         const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);
+        if (COUNT) { w_blocked += __popcll(__ballot(pend != 0 && node < 0 && node != kDone)); w_pend += __popcll(__ballot(pend != 0 && node == kDone)); }
         if ((int)__popcll(mt) >= tth || __ballot(node >= 0) == 0ull) {
-            if (COUNT) w_t += __popcll(mt);
+            if (COUNT) { w_t += __popcll(mt); ++w_tblocks; }
             if (need_t) {
                 const uint32_t ref = ~(uint32_t)pend;              // (first << 3) | (remaining - 1)
                 const float4* tp = tris + (size_t)(ref >> 3) * 3;
@@ -531,6 +547,10 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             atomicAdd(&counters[7], (unsigned long long)w_rounds);      // waves      <- scheduling rounds
             atomicAdd(&counters[5], (unsigned long long)w_i);           // wave_max_nodes <- lanes active in interior blocks
             atomicAdd(&counters[6], (unsigned long long)w_t);           // wave_max_tris  <- lanes active in triangle blocks
+            atomicAdd(&counters[8], (unsigned long long)w_idle);        // lanes without a ray (waiting for the next refill), summed over rounds
+            atomicAdd(&counters[9], (unsigned long long)w_blocked);     // lanes holding a parked leaf AND standing on a second one
+            atomicAdd(&counters[10], (unsigned long long)w_pend);       // lanes with an empty stack waiting for the triangle block
+            atomicAdd(&counters[11], (unsigned long long)w_tblocks);    // rounds in which the triangle block ran
         }
     }
 }

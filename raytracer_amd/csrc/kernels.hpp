@@ -112,6 +112,6 @@ constexpr int kWorkSlots = 4;     // chunk-cursor sets behind the counters: one 
 constexpr int kCursorStride = 16;       // u64 words between chunk cursors: one 128-B line each, so they sit in different L2 channels
 constexpr int kWorkWords = 9 * kCursorStride;   // 8 cursors + the mask of exhausted eighths
 constexpr int kCountersPad = 16;        // the counters take the first line of the buffer, the cursor sets follow
-constexpr int kNumCounters = 8;   // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves
+constexpr int kNumCounters = 12;  // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves, + 4 strip-kernel scheduling probes
 
 }  // namespace rt

@@ -810,6 +810,7 @@ int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) try {
     RT_HIP(c, hipMemcpy(v, r.d_counters, sizeof v, hipMemcpyDeviceToHost));
     out->rays = v[0]; out->box_tests = v[1]; out->nodes = v[2]; out->tri_tests = v[3]; out->sphere_tests = v[4];
     out->wave_max_nodes = v[5]; out->wave_max_tris = v[6]; out->waves = v[7];
+    out->idle_lane_rounds = v[8]; out->blocked_lane_rounds = v[9]; out->drained_lane_rounds = v[10]; out->tri_rounds = v[11];
     if (reset) RT_HIP(c, hipMemset(r.d_counters, 0, sizeof v));
     return RT_OK;
 } RT_ABI_CATCH(c)

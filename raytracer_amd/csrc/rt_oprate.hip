@@ -32,13 +32,31 @@ KERNEL(k_rcp,    "v_rcp_f32 %0, %0", "v"(a))
 KERNEL(k_cmp,    "v_cmp_lt_f32 vcc, %0, %1", "v"(a))
 KERNEL(k_cvtpk,  "v_cvt_pkrtz_f16_f32 %0, %0, %1", "v"(a))
 KERNEL(k_sdwa,   "v_cvt_f32_ubyte0_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2", "v"(a))
+KERNEL(k_fmamix, "v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]", "v"(a), "v"(b))          // src0 read as f16 (high half)
+KERNEL(k_pkminu, "v_pk_min_u16 %0, %0, %1", "v"(a))
+KERNEL(k_ldexp,  "v_ldexp_f32 %0, %0, %1", "v"(a))
+KERNEL(k_andor,  "v_and_or_b32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_lshlor, "v_lshl_or_b32 %0, %0, 2, %1", "v"(a))
+KERNEL(k_align,  "v_alignbit_b32 %0, %0, %0, 16")
+KERNEL(k_madu24, "v_mad_u32_u24 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_med3,   "v_med3_f32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_cvtf16, "v_cvt_f32_f16 %0, %0")
+KERNEL(k_bfi,    "v_bfi_b32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_cmpu,   "v_cmp_lt_u32 vcc, %0, %1", "v"(a))
+KERNEL(k_cndm2,  "v_cndmask_b32 %0, %1, %2, vcc", "v"(a), "v"(b))                          // no chain through the destination
+KERNEL(k_subf,   "v_sub_f32 %0, %0, %1", "v"(a))
+KERNEL(k_xor,    "v_xor_b32 %0, %0, %1", "v"(a))
+KERNEL(k_or3,    "v_or3_b32 %0, %0, %1, %2", "v"(a), "v"(b))
 typedef void (*kfn)(float*, float, float);
 int main() {
     float* out; CHECK(hipMalloc(&out, 64));
     int cus = 0; CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     struct { const char* n; kfn f; } ks[] = { {"v_fma_f32", k_fma}, {"v_mul_f32", k_mul}, {"v_add_f32", k_add}, {"v_min_f32", k_min}, {"v_max3_f32", k_max3},
         {"v_cvt_f32_ubyte1", k_cvtub}, {"v_cvt_f32_u32", k_cvtu}, {"v_and_b32", k_and}, {"v_add_u32", k_addu}, {"v_min_u32", k_minu}, {"v_lshlrev_b32", k_lshl},
-        {"v_cndmask_b32", k_cndm}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_cmp_lt_f32", k_cmp}, {"v_cvt_pkrtz", k_cvtpk}, {"cvt_ubyte_sdwa", k_sdwa} };
+        {"v_cndmask_b32", k_cndm}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_cmp_lt_f32", k_cmp}, {"v_cvt_pkrtz", k_cvtpk}, {"cvt_ubyte_sdwa", k_sdwa},
+        {"v_fma_mix_f32", k_fmamix}, {"v_pk_min_u16", k_pkminu}, {"v_ldexp_f32", k_ldexp}, {"v_and_or_b32", k_andor},
+        {"v_lshl_or_b32", k_lshlor}, {"v_alignbit_b32", k_align}, {"v_mad_u32_u24", k_madu24}, {"v_med3_f32", k_med3}, {"v_cvt_f32_f16", k_cvtf16},
+        {"v_bfi_b32", k_bfi}, {"v_cmp_lt_u32", k_cmpu}, {"v_cndmask(no chain)", k_cndm2}, {"v_sub_f32", k_subf}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3} };
     const int grid = cus * 32;
     for (auto& k : ks) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
