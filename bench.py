@@ -240,6 +240,7 @@ def main():
                 "traffic": pmc.get("k_trace_hbm_bytes_per_launch"), "flops_per_ray": round(fl_b, 1), "work_per_ray": w_b,
                 "launch_ms": round(ms_btrace, 4), "rays_per_launch": int(live_b),
                 "measured_valu_busy_pct": pmc.get("k_trace_valu_busy_pct"),
+                "measured_valu_inst_per_simd_cycle": pmc.get("k_trace_valu_inst_per_simd_cycle"),
                 "measured_lane_utilisation_pct": pmc.get("k_trace_lane_utilisation_pct"),
                 "note": "SURVEY 8d flop count (24 per box test, 53 per triangle test) over the HIP-event launch time; "
                         "never MFMA.  Most issued VALU instructions are converts/compares/selects, so the issue-slot "
@@ -266,6 +267,10 @@ def main():
         "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
                   "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
                   "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0")},
+        # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints
+        "launch": {"dynamic_lds_bytes_per_block": {"k_primary": stats["stack_entries"] * 1024,
+                                                   "k_trace_strip": min(stats["stack_entries"], 20) * 1024},
+                   "stack_entries": stats["stack_entries"], "lds_stack_option": 20},
         "roofline": roofline, "roofline_hbm": roofline_hbm,
         "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_shade_ms": round(ms_primary, 4),
                     "primary_work_per_ray": w_p, "primary_tflops": round(fl_p * n_real_local / (ms_primary * 1e-3) / 1e12, 3),

@@ -89,6 +89,10 @@ typedef struct {
     float    build_ms;         /* host BVH build + flatten */
     float    upload_ms;        /* H2D copies */
     uint64_t device_bytes;     /* per replica */
+    uint32_t stack_entries;    /* traversal-stack entries per ray the flattened tree can need, sentinel included: the tile
+                                  kernel's dynamic LDS is stack_entries * 1 KiB per 256-thread block, the ray-buffer kernel's
+                                  min(stack_entries, RT_OPT_LDS_STACK) * 1 KiB */
+    uint32_t reserved;
 } rt_scene_stats;
 
 /* Work counters of the instrumented kernel (B, N, T per ray). */
@@ -260,6 +264,13 @@ void     rt_gen_random_rays(uint64_t seed, uint64_t first, uint64_t n, rt_ray* o
  * Camera::updateCameraVectors (src/application/Camera.h:36-41). */
 void     rt_camera_look_at(const float pos[3], const float look_at[3], float fov_deg, float aspect,
                            void* camera_ubo112);
+/* the camera mutators of src/application/Camera.h:56-90 applied to a 112-byte UBO in place -- what the
+ * reference's GLFW callbacks (src/application/Application.h:53-174) do between frames; pass the result to rt_set_camera.
+ * rt_camera_move = moveForward / moveRight / moveUp (position and look-at point translate together along the basis
+ * vector), rt_camera_rotate = rotateAroundUp (about worldUp) / rotateAroundRight, angles in degrees; zero arguments
+ * are skipped.  The C++ class itself (same member names as the reference's Camera) is raytracer_amd/host/rt_camera.hpp. */
+void     rt_camera_move(void* camera_ubo112, float forward, float right, float up);
+void     rt_camera_rotate(void* camera_ubo112, float around_up_deg, float around_right_deg);
 
 /* minimal Wavefront OBJ reader -> the reference's 144-B Triangle records (src/math/Triangle.h),
  * ready for rt_scene_upload.  The reference has no loader (its geometry is the literal scene of

@@ -15,7 +15,7 @@ from . import _abi
 from ._abi import rt_counters, rt_scene_stats
 
 __all__ = ["Renderer", "TRIANGLE", "SPHERE", "LIGHT", "CAMERA", "RAY", "HIT", "MATERIAL", "VERTEX",
-           "MISS", "SPHERE_BIT", "camera_look_at", "default_camera", "lib"]
+           "MISS", "SPHERE_BIT", "camera_look_at", "camera_move", "camera_rotate", "default_camera", "lib"]
 
 MISS = 0xFFFFFFFF
 SPHERE_BIT = 0x80000000
@@ -76,6 +76,20 @@ def camera_look_at(pos, look_at, fov_deg, aspect):
     l = (C.c_float * 3)(*look_at)
     lib().rt_camera_look_at(p, l, C.c_float(fov_deg), C.c_float(aspect), _ptr(ubo))
     return ubo
+
+
+def camera_move(ubo, forward=0.0, right=0.0, up=0.0):
+    """Camera::moveForward / moveRight / moveUp (src/application/Camera.h:56-75) on a CAMERA record; returns a new record."""
+    out = np.ascontiguousarray(ubo).copy()
+    lib().rt_camera_move(_ptr(out), C.c_float(forward), C.c_float(right), C.c_float(up))
+    return out
+
+
+def camera_rotate(ubo, around_up_deg=0.0, around_right_deg=0.0):
+    """Camera::rotateAroundUp / rotateAroundRight (src/application/Camera.h:77-91), degrees; returns a new record."""
+    out = np.ascontiguousarray(ubo).copy()
+    lib().rt_camera_rotate(_ptr(out), C.c_float(around_up_deg), C.c_float(around_right_deg))
+    return out
 
 
 def load_obj(path, material=None):

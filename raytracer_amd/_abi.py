@@ -18,7 +18,7 @@ class rt_scene_stats(C.Structure):
                 ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
                 ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("sah_cost", C.c_float), ("build_ms", C.c_float), ("upload_ms", C.c_float),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("stack_entries", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class rt_counters(C.Structure):
@@ -69,6 +69,8 @@ SYMBOLS = [
     ("rt_gen_soup", _U32, [_U64, _U32, C.c_float, _P, _U32]),
     ("rt_gen_random_rays", None, [_U64, _U64, _U64, _P]),
     ("rt_camera_look_at", None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, _P]),
+    ("rt_camera_move", None, [_P, C.c_float, C.c_float, C.c_float]),
+    ("rt_camera_rotate", None, [_P, C.c_float, C.c_float]),
     ("rt_load_obj", _I, [C.c_char_p, _P, _P, _U64, C.POINTER(_U64)]),
 ]
 

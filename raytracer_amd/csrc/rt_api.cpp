@@ -500,6 +500,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
         }
     }
     st.node_bytes = 64; st.tri_bytes = 48;
+    st.stack_entries = hs.stack_need + 2;
     st.sah_cost = hs.sah_cost;
     st.build_ms = (float)(t1 - t0); st.upload_ms = (float)(t2 - t1);
     st.device_bytes = (uint64_t)hs.nodes.size() * 4 + (uint64_t)hs.tri48.size() * 4 + (uint64_t)hs.nrm48.size() * 4 + (uint64_t)hs.sph.size() * 4;

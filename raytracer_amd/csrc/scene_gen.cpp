@@ -6,6 +6,7 @@
 // "soup" scenes are the synthetic inputs of SURVEY.md 8(d) (real Bunny/Sponza meshes are not in the
 // reference and cannot be fetched).
 #include "../../include/raytracer_amd.h"
+#include "../host/rt_camera.hpp"
 #include "../host/rt_types.hpp"
 
 #include <algorithm>
@@ -238,6 +239,27 @@ void rt_camera_look_at(const float pos[3], const float look_at[3], float fov_deg
     c.m_fov = fov_deg; c.m_aspectRatio = aspect;
     c.m_nearPlane = 0.1f; c.m_farPlane = 100.0f;           // VkRenderer.cpp:10-11 (unused by the shader)
     std::memcpy(ubo, &c, sizeof c);
+}
+
+// Camera mutators of the reference (src/application/Camera.h:56-90) on a 112-byte UBO in place, for hosts without the C++
+// header (raytracer_amd/host/rt_camera.hpp holds the class itself): what the GLFW callbacks do between frames
+// (src/application/Application.h:53-174) before updateUniformBuffer hands the UBO over.  Order within one call:
+// moveForward, moveRight, moveUp / rotateAroundUp, rotateAroundRight; zero arguments are skipped.
+void rt_camera_move(void* ubo, float forward, float right, float up) {
+    Camera c;
+    std::memcpy(&c.m_cameraUBO, ubo, sizeof(CameraUBO));
+    if (forward != 0.0f) c.moveForward(forward);
+    if (right != 0.0f) c.moveRight(right);
+    if (up != 0.0f) c.moveUp(up);
+    std::memcpy(ubo, &c.m_cameraUBO, sizeof(CameraUBO));
+}
+
+void rt_camera_rotate(void* ubo, float around_up_deg, float around_right_deg) {
+    Camera c;
+    std::memcpy(&c.m_cameraUBO, ubo, sizeof(CameraUBO));
+    if (around_up_deg != 0.0f) c.rotateAroundUp(around_up_deg);
+    if (around_right_deg != 0.0f) c.rotateAroundRight(around_right_deg);
+    std::memcpy(ubo, &c.m_cameraUBO, sizeof(CameraUBO));
 }
 
 }  // extern "C"

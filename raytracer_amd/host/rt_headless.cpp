@@ -7,7 +7,11 @@
 // the headless form of the presentation hook.  A Wavefront OBJ can replace the three
 // Cornell spheres.
 //
-// usage: rt_headless [width height [out.ppm [spp bounces [mesh.obj]]]]
+// The camera is the reference's interactive Camera (rt_camera.hpp, src/application/Camera.h): optional yaw / pitch (degrees)
+// and dolly arguments apply rotateAroundUp / rotateAroundRight / moveForward before the frame, the way the GLFW callbacks
+// (src/application/Application.h:53-174) would between frames.
+//
+// usage: rt_headless [width height [out.ppm [spp bounces [mesh.obj|- [yaw_deg pitch_deg dolly]]]]]
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -15,6 +19,7 @@
 #include <vector>
 
 #include "raytracer.hpp"
+#include "rt_camera.hpp"
 
 int main(int argc, char** argv) {
     try {
@@ -28,7 +33,7 @@ int main(int argc, char** argv) {
         rt_gen_cornell_spheres(spheres.data(), (uint32_t)spheres.size());
         std::vector<rt::Light> lights;                                         // VkRenderer.cpp:252-258: none
         const uint32_t spp = argc > 5 ? (uint32_t)std::atoi(argv[4]) : 0, bounces = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 0;
-        if (argc > 6) {                                                        // mesh instead of the spheres
+        if (argc > 6 && std::string(argv[6]) != "-") {                         // mesh instead of the spheres
             const std::vector<rt::Triangle> mesh = rt::Engine::loadObj(argv[6]);
             tris.insert(tris.end(), mesh.begin(), mesh.end());
             spheres.clear();
@@ -36,9 +41,15 @@ int main(int argc, char** argv) {
 
         rt::Engine engine({0});
         engine.upload(tris, spheres, lights);
-        rt::CameraUBO cam;
-        const float pos[3] = {0.0f, 4.0f, 1.0f}, look[3] = {0.0f, 0.0f, 1.0f};  // VkRenderer.cpp:3-12
-        rt_camera_look_at(pos, look, 45.0f, (float)w / (float)h, &cam);
+        // VkRenderer::VkRenderer (VkRenderer.cpp:3-12): position (0,4,1), lookAt (0,0,1), up (0,0,-1), vfov 45, near 0.1, far 100
+        rt::Camera camera({0.0f, 4.0f, 1.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, -1.0f}, 45.0f, (float)w / (float)h, 0.1f, 100.0f);
+        if (argc > 9) {
+            camera.rotateAroundUp((float)std::atof(argv[7]));
+            camera.rotateAroundRight((float)std::atof(argv[8]));
+            camera.moveForward((float)std::atof(argv[9]));
+        }
+        rt::Camera::UniformBufferObject cam;
+        camera.updateCameraUBO(cam, 0.0f);                                     // VkRenderer::updateUniformBuffer, :855-862
         engine.setCamera(&cam);
 
         std::ofstream f(path, std::ios::binary);

@@ -1,8 +1,24 @@
 """Summarise rocprofv3 output (kernel-trace stats + PMC passes) into profiles/<tag>_summary.{json,md}.
 
-usage: python scripts/summarize_prof.py <tag> <kernel_trace_dir> <pmc_dir>
+usage: python scripts/summarize_prof.py <tag> <kernel_trace_dir> <pmc_dir> [bench.json]
 Corrections applied exactly as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE (KiB) is doubled for wide
 coalesced reads on gfx950 (it tallies 128-B requests at 64 B); WRITE_SIZE (KiB) is taken as is.
+
+Derived columns and the counters they come from (rocprofv3 sums every counter over the chip; SQ_* "cycles" are quad-cycles,
+GRBM_GUI_ACTIVE is the sum of the 8 XCDs' busy cycles; gfx950 has no derived-metric section, these are the gfx94x forms):
+  cycles            = GRBM_GUI_ACTIVE / 8                         shader cycles of the launch
+  VALU busy %       = min(100, raw) with raw = 100 * 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * cycles).  SQ_ACTIVE_INST_VALU
+                      charges every wave 4 cycles per VALU instruction, while fma/mul/add/and/mov-class instructions of
+                      DIFFERENT waves issue 2.2-3 cycles apart on a SIMD (rt_oprate, profiles/r01g_peaks.md), so the raw
+                      sum can pass 100: raw >= 100 means the SIMDs' VALU issue ports were never idle.  raw is kept beside it.
+  VALU inst / SIMD-cycle = SQ_INSTS_VALU / (1024 * cycles)        ceiling 0.25 for the 4-cycle classes (min/max, cvt, cmp,
+                      cndmask, shifts, packed fma), ~0.4 for the 2.4-cycle classes
+  lane util %       = 100 * SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+  waves/CU          = 4 * SQ_WAVE_CYCLES / cycles / 256
+VGPRs, scratch and the compiler's occupancy bound come from `make -C raytracer_amd/csrc resources`
+(profiles/<tag>_kernel_resources.txt), not from rocprofv3: its VGPR_Count column reads 40 for a kernel that allocates 80,
+and its LDS_Block_Size column shows only static LDS (0 here: the traversal stacks are dynamic LDS, a launch argument).
+Dynamic LDS per 256-thread block is taken from the bench line's `launch` object when a bench.json is given.
 """
 import csv
 import glob
@@ -13,10 +29,24 @@ from collections import defaultdict
 
 tag, kdir, pdir = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+launch = {}
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+    try:
+        launch = json.loads([l for l in open(sys.argv[4]).read().splitlines() if l.startswith("{")][-1]).get("launch", {})
+    except Exception:
+        launch = {}
+
+
+def dyn_lds(kernel):
+    for key, val in launch.get("dynamic_lds_bytes_per_block", {}).items():
+        if kernel.startswith(key):
+            return val
+    return None
+
 
 
 def short(name):
-    for k in ("k_trace", "k_primary", "k_bounce", "k_shadow", "k_shade", "k_resolve"):
+    for k in ("k_trace", "k_primary", "k_bounce", "k_shadow", "k_shade", "k_resolve", "k_bin"):
         if k in name:
             t = name[name.index(k):]
             return t[: t.index("(")] if "(" in t else t
@@ -57,9 +87,15 @@ for k, ctrs in pmc.items():
         der["hbm_pct_of_8TBps"] = 100 * der["hbm_GBps"] / 8000
     if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
         der["l2_hit_pct"] = 100 * m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
-    if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"] > 0:
-        # gfx94x formula: VALUBusy = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMDs / busy cycles (per-SE busy cycles summed)
-        der["valu_busy_pct"] = 100 * m["SQ_ACTIVE_INST_VALU"] * 4 / 4 / (m["GRBM_GUI_ACTIVE"] / 8 * 256) if "GRBM_GUI_ACTIVE" in m else None
+    if "SQ_ACTIVE_INST_VALU" in m and m.get("GRBM_GUI_ACTIVE", 0) > 0:
+        cycles = m["GRBM_GUI_ACTIVE"] / 8
+        raw = 100 * 4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles)
+        der["valu_busy_raw_pct"] = raw
+        der["valu_busy_pct"] = min(100.0, raw)
+        if "SQ_INSTS_VALU" in m:
+            der["valu_inst_per_simd_cycle"] = m["SQ_INSTS_VALU"] / (1024 * cycles)
+        if "avg_us" in d:
+            der["effective_clock_GHz"] = cycles / (d["avg_us"] * 1e3)
     if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m and m["SQ_ACTIVE_INST_VALU"] > 0:
         der["valu_lane_utilisation_pct"] = 100 * m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64)
     if "SQ_LDS_BANK_CONFLICT" in m and "SQ_LDS_IDX_ACTIVE" in m and m["SQ_LDS_IDX_ACTIVE"] > 0:
@@ -74,6 +110,7 @@ for k, ctrs in pmc.items():
             der["wave_issuing_pct"] = 100 * m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m and m["SQ_WAVES"] > 0:
         der["valu_insts_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
+    d["dynamic_lds_bytes_per_block"] = dyn_lds(k)
     d["derived"] = {a: (round(b, 3) if isinstance(b, float) else b) for a, b in der.items()}
     out["kernels"][k] = d
 for k, v in kern.items():
@@ -84,17 +121,20 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
 with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary `{tag}`\n\nkernel-trace: `{kdir}`; PMC passes: `{pdir}` (one pass per run, scripts/pmc_passes.sh)\n\n")
-    f.write("| kernel | calls | avg us | VGPR | LDS B | HBM GB/s (% of 8 TB/s) | L2 hit % | VALU busy % | lane util % | waves/CU (occ %) | LDS conflict % | wait-any % |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+    f.write("Formulas and counters: header of `scripts/summarize_prof.py`.  VGPRs / scratch: `profiles/%s_kernel_resources.txt`.\n\n" % tag)
+    f.write("| kernel | calls | avg us | dyn. LDS B/block | HBM GB/s (% of 8 TB/s) | L2 hit % | VALU busy % (raw) | VALU inst/SIMD-cycle | lane util % | waves/CU (occ %) | LDS conflict % | wait-any % |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
     for k, d in out["kernels"].items():
         e = d.get("derived", {})
         g = lambda x, fmt="{:.1f}": fmt.format(e[x]) if e.get(x) is not None else "-"
-        f.write(f"| `{k}` | {d.get('calls','-')} | {d.get('avg_us',0):.1f} | {d.get('vgpr','-')} | {d.get('lds','-')} | {g('hbm_GBps')} ({g('hbm_pct_of_8TBps')}) | {g('l2_hit_pct')} | {g('valu_busy_pct')} | {g('valu_lane_utilisation_pct')} | {g('mean_waves_per_cu')} ({g('occupancy_pct_of_32_waves')}) | {g('lds_bank_conflict_pct_of_lds_cycles','{:.2f}')} | {g('wave_wait_any_pct')} |\n")
+        lds = d.get("dynamic_lds_bytes_per_block")
+        f.write(f"| `{k}` | {d.get('calls','-')} | {d.get('avg_us',0):.1f} | {lds if lds is not None else '-'} | {g('hbm_GBps')} ({g('hbm_pct_of_8TBps')}) | {g('l2_hit_pct')} | {g('valu_busy_pct')} ({g('valu_busy_raw_pct')}) | {g('valu_inst_per_simd_cycle','{:.3f}')} | {g('valu_lane_utilisation_pct')} | {g('mean_waves_per_cu')} ({g('occupancy_pct_of_32_waves')}) | {g('lds_bank_conflict_pct_of_lds_cycles','{:.2f}')} | {g('wave_wait_any_pct')} |\n")
 # what bench.py reads for roofline.traffic
 cands = [d for k, d in out["kernels"].items() if k.startswith("k_trace") and "hbm_bytes" in d.get("derived", {})]
 kt = max(cands, key=lambda d: d.get("total_ms", 0.0)) if cands else None     # the bounce closest-hit launch
 if kt and "hbm_bytes" in kt.get("derived", {}):
     json.dump({"tag": tag, "k_trace_hbm_bytes_per_launch": kt["derived"]["hbm_bytes"],
                "k_trace_valu_busy_pct": kt["derived"].get("valu_busy_pct"),
+               "k_trace_valu_inst_per_simd_cycle": kt["derived"].get("valu_inst_per_simd_cycle"),
                "k_trace_lane_utilisation_pct": kt["derived"].get("valu_lane_utilisation_pct"),
                "k_trace_l2_hit_pct": kt["derived"].get("l2_hit_pct")},
               open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"))
