@@ -204,3 +204,126 @@ def translated(tris, offset):
     for v in ("v0", "v1", "v2"):
         t[v]["position"] = (t[v]["position"].astype(np.float32) + off).astype(np.float32)
     return t
+
+
+# ---- a harder "Sponza-class" stand-in: a colonnade hall -----------------------------------------------------------
+def _mesh(p0, p1, p2, albedo=(0.7, 0.7, 0.7), emission=None, strength=0.0, roughness=0.6, metallic=0.0):
+    """TRIANGLE records with flat (geometric) normals from three (n, 3) float arrays."""
+    p0, p1, p2 = (np.asarray(a, dtype=np.float32).reshape(-1, 3) for a in (p0, p1, p2))
+    n = np.cross((p1 - p0).astype(np.float64), (p2 - p0).astype(np.float64))
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-300), (0.0, 0.0, 1.0)).astype(np.float32)
+    t = np.zeros(len(p0), dtype=TRIANGLE)
+    for name, q in (("v0", p0), ("v1", p1), ("v2", p2)):
+        t[name]["position"] = q
+        t[name]["normal"] = n
+    m = t["material"]
+    m["albedo"], m["roughness"], m["metallic"] = albedo, roughness, metallic
+    if emission is not None:
+        m["emission"], m["emissionStrength"] = emission, strength
+    return t
+
+
+def _grid(P, **mat):
+    """Two triangles per cell of a (nu+1, nv+1, 3) grid of points."""
+    P = np.asarray(P, dtype=np.float32)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    r = lambda x: x.reshape(-1, 3)
+    return cat([_mesh(r(a), r(b), r(c), **mat), _mesh(r(a), r(c), r(d), **mat)])
+
+
+def _box(lo, hi, **mat):
+    """Closed axis-aligned box, 12 triangles, outward faces."""
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    c = np.array([(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)], dtype=np.float32)
+    f = [(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (2, 3, 7), (2, 7, 6), (1, 2, 6), (1, 6, 5), (3, 0, 4), (3, 4, 7)]
+    f = np.array(f)
+    return _mesh(c[f[:, 0]], c[f[:, 1]], c[f[:, 2]], **mat)
+
+
+def colonnade(detail=1.0):
+    """A second, harder C3-class stand-in ("colonnade", ~262 k triangles at detail 1): a 36 x 14 x 10 hall with what the
+    sphere grid of sponza_class() lacks -- long thin floor / wall / beam triangles beside a finely tiled mosaic
+    (triangle edge lengths from 36 down to 0.03: more than 100:1), two rows of fluted columns with capitals, arches
+    between them, a barrel vault, rows of thin balusters, and wavy hanging drapes (thin, overlapping, open surfaces).
+    Emissive window panels light it.  NOT Sponza; same interface as sponza_class(): (tris, spheres, lights, camera)."""
+    k = lambda n: max(2, int(round(n * detail)))
+    parts = []
+    stone, dark, cloth = (0.72, 0.68, 0.6), (0.35, 0.33, 0.3), (0.6, 0.15, 0.12)
+    L, Wd, Ht = 36.0, 14.0, 10.0
+    # floor: 24 strips 36 m long and 0.58 m wide (two triangles each: aspect ratio 60:1) ...
+    ys = np.linspace(-Wd / 2, Wd / 2, 25, dtype=np.float32)
+    P = np.zeros((2, 25, 3), dtype=np.float32); P[0, :, 0], P[1, :, 0] = -L / 2, L / 2; P[:, :, 1] = ys
+    parts.append(_grid(P, albedo=stone))
+    # ... and a finely tiled mosaic lying 2 mm above it (0.03 m tiles)
+    n = k(150)
+    u = np.linspace(-2.25, 2.25, n + 1, dtype=np.float32)
+    X, Y = np.meshgrid(u + 4.0, u, indexing="ij")
+    parts.append(_grid(np.stack([X, Y, np.full_like(X, 0.002)], -1), albedo=(0.2, 0.3, 0.6), roughness=0.2))
+    # walls: long thin horizontal courses (36 m x 0.5 m), end walls in two triangles each
+    zs = np.linspace(0.0, Ht, 21, dtype=np.float32)
+    for y, flip in ((-Wd / 2, False), (Wd / 2, True)):
+        P = np.zeros((2, 21, 3), dtype=np.float32); P[0, :, 0], P[1, :, 0] = (-L / 2, L / 2) if not flip else (L / 2, -L / 2)
+        P[:, :, 1] = y; P[:, :, 2] = zs
+        parts.append(_grid(P, albedo=stone))
+    for x, flip in ((-L / 2, True), (L / 2, False)):
+        P = np.zeros((2, 2, 3), dtype=np.float32); P[0, :, 1], P[1, :, 1] = (-Wd / 2, Wd / 2) if not flip else (Wd / 2, -Wd / 2)
+        P[:, :, 0] = x; P[:, 0, 2], P[:, 1, 2] = 0.0, Ht
+        parts.append(_grid(P, albedo=stone))
+    # emissive window panels high on the long walls
+    for i in range(6):
+        x0 = -15.0 + 6.0 * i
+        parts.append(_box((x0, -Wd / 2 + 0.01, 6.0), (x0 + 2.0, -Wd / 2 + 0.05, 8.5), albedo=(1, 1, 1), emission=(1.0, 0.95, 0.85), strength=6.0))
+        parts.append(_box((x0, Wd / 2 - 0.05, 6.0), (x0 + 2.0, Wd / 2 - 0.01, 8.5), albedo=(1, 1, 1), emission=(0.85, 0.9, 1.0), strength=4.0))
+    # two rows of 12 fluted columns (radius 0.45 with 16 flutes), base and capital boxes
+    seg, rings = k(64), k(20)
+    th = np.linspace(0.0, 2 * np.pi, seg + 1)
+    zc = np.linspace(0.4, 5.6, rings + 1)
+    col_x = np.linspace(-15.0, 15.0, 12)
+    for cy in (-4.0, 4.0):
+        for cx in col_x:
+            r = 0.45 + 0.03 * np.cos(16 * th)
+            P = np.stack([np.broadcast_to(cx + r * np.cos(th), (rings + 1, seg + 1)), np.broadcast_to(cy + r * np.sin(th), (rings + 1, seg + 1)),
+                          np.broadcast_to(zc[:, None], (rings + 1, seg + 1))], -1)
+            parts.append(_grid(P, albedo=stone, roughness=0.4))
+            parts.append(_box((cx - 0.6, cy - 0.6, 0.0), (cx + 0.6, cy + 0.6, 0.4), albedo=dark))
+            parts.append(_box((cx - 0.6, cy - 0.6, 5.6), (cx + 0.6, cy + 0.6, 6.0), albedo=dark))
+    # arches between neighbouring columns of a row: a square profile swept along a half circle
+    aseg = k(64)
+    phi = np.linspace(0.0, np.pi, aseg + 1)
+    span = (col_x[1] - col_x[0]) / 2
+    for cy in (-4.0, 4.0):
+        for i in range(len(col_x) - 1):
+            mx = (col_x[i] + col_x[i + 1]) / 2
+            prof = np.array([(-0.25, -0.2), (0.25, -0.2), (0.25, 0.2), (-0.25, 0.2), (-0.25, -0.2)])      # (dy, dr)
+            rr = np.broadcast_to((span - 0.25) + prof[:, 1][None, :], (aseg + 1, len(prof)))
+            P = np.stack([mx - rr * np.cos(phi)[:, None], np.broadcast_to(cy + prof[:, 0][None, :], rr.shape), 6.0 + rr * np.sin(phi)[:, None]], -1)
+            parts.append(_grid(P, albedo=stone))
+    # barrel vault over the hall
+    nv_, nl = k(56), k(220)
+    a = np.linspace(0.0, np.pi, nv_ + 1)
+    xs = np.linspace(-L / 2, L / 2, nl + 1)
+    P = np.stack([np.broadcast_to(xs[:, None], (nl + 1, nv_ + 1)), np.broadcast_to((Wd / 2) * np.cos(a)[None, :], (nl + 1, nv_ + 1)),
+                  np.broadcast_to(Ht - 3.0 + 3.0 * np.sin(a)[None, :], (nl + 1, nv_ + 1))], -1)
+    parts.append(_grid(P, albedo=(0.8, 0.78, 0.7)))
+    # roof beams: 30 boxes 14 m long and 0.15 m thick
+    for x in np.linspace(-17.0, 17.0, 30):
+        parts.append(_box((x - 0.075, -Wd / 2, 6.6), (x + 0.075, Wd / 2, 6.8), albedo=dark))
+    # balustrades along both rows: 2 x 300 thin balusters (0.05 x 0.05 x 0.9) under a 30 m rail
+    for cy in (-5.2, 5.2):
+        for x in np.linspace(-15.0, 15.0, 300):
+            parts.append(_box((x - 0.025, cy - 0.025, 0.0), (x + 0.025, cy + 0.025, 0.9), albedo=dark))
+        parts.append(_box((-15.0, cy - 0.05, 0.9), (15.0, cy + 0.05, 1.0), albedo=dark))
+    # hanging drapes between the columns: wavy open sheets, long thin cells (0.02 x 0.12)
+    du, dv = k(96), k(48)
+    uu, vv = np.meshgrid(np.linspace(0.0, 1.0, du + 1), np.linspace(0.0, 1.0, dv + 1), indexing="ij")
+    for j, cy in enumerate((-4.0, 4.0)):
+        for i in range(0, len(col_x) - 1, 2):
+            x0 = col_x[i] + 0.6
+            X = x0 + uu * (col_x[i + 1] - col_x[i] - 1.2)
+            Yd = cy + 0.18 * np.sin(uu * 9 * np.pi + 0.7 * i) * (1.0 - 0.5 * vv) + 0.03 * np.sin(vv * 11.0 + i + j)
+            Z = 5.4 - vv * (3.6 + 0.4 * np.sin(uu * 3.0 + i))
+            parts.append(_grid(np.stack([X, Yd, Z], -1), albedo=cloth, roughness=0.9))
+    tris = cat(parts)
+    cam = camera_look_at((-16.5, -1.2, 1.7), (6.0, 1.5, 3.2), 65.0, 3840.0 / 2160.0)
+    return tris, np.zeros(0, dtype=SPHERE), np.zeros(0, dtype=LIGHT), cam

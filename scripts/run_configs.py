@@ -1,7 +1,7 @@
 """Runs the BASELINE.json configs C1..C5 on ONE MI355X and prints one JSON line per config (results table of
 DESIGN.md).  Parity gates (prim-ID mismatches against the oracle / the brute-force HIP kernel) ride along.
 
-usage: python scripts/run_configs.py [c1 c2 c3 c4 c5] [--soup N] [--rays N]
+usage: python scripts/run_configs.py [c1 c2 c3 c3b c4 c5] [--soup N] [--rays N]
 """
 import argparse
 import json
@@ -95,6 +95,53 @@ def c2():
                          "work_primary": counters_of(r, lambda: r.trace_primary_dev(w, h, hits, rays)),
                          "bvh": {"nodes": st["n_nodes"], "depth": st["max_depth"], "build_ms": round(st["build_ms"], 1)},
                          "parity": par}
+    out(res)
+
+
+def c3(which):
+    """The bench frame (4K x 4 spp: primary + segment 0, bounce closest hit, last segment + resolve) on the sphere-grid
+    stand-in of SURVEY 8(d) ("sponza") or on the harder colonnade hall ("colonnade"), with the work counters and parity gates."""
+    tris, sph, lights, cam = scenes.sponza_class() if which == "sponza" else scenes.colonnade()
+    w, h, spp = 3840, 2160, 4
+    n = w * h * spp
+    label = ("C3 sponza-class stand-in (8x8 sphereGeometry(45,45) in a room)" if which == "sponza" else
+             "C3b colonnade hall (long thin floor/wall/beam triangles, fluted columns, arches, vault, balusters, drapes; edge lengths 0.014..36)")
+    res = {"config": f"{label}, {len(tris)} tris, 3840x2160 x 4 spp primary + 1 bounce + shading"}
+    with rt.Renderer((0,)) as r:
+        st = r.create_data(tris, sph, lights); r.update_camera(cam)
+        rays, brays, phits, bhits, thr, rad = f32(n * 8), f32(n * 8), f32(n * 4), f32(n * 4), f32(n * 4), f32(n * 4)
+        fb = torch.empty(w * h, dtype=torch.int32, device=dev)
+        prim = lambda: r.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr, rad, brays, spp=spp, seed=1, jitter=True, shade_seed=2)
+        bounce = lambda: r.trace_dev(brays, n, bhits)
+        last = lambda: r.shade_resolve_dev(brays, bhits, n, spp, thr, rad, None, fb)
+        prim(); bounce(); last(); torch.cuda.synchronize()
+        ms_p, ms_b, ms_l = timeit(prim, 10), timeit(bounce, 10), timeit(last, 10)
+        unf = lambda: r.trace_primary_dev(w, h, phits, rays, spp=spp, seed=1, jitter=True)
+        wp = counters_of(r, unf)
+        wb = counters_of(r, bounce)
+        live_b = int((brays.view(-1, 8)[:, 7] > 0).sum())
+        res.update({"primary_shade_ms": round(ms_p, 3), "bounce_ms": round(ms_b, 3), "shade_resolve_ms": round(ms_l, 3),
+                    "frame_ms": round(ms_p + ms_b + ms_l, 3), "Mrays_s": round((n + live_b) / (ms_p + ms_b + ms_l) / 1e3, 1),
+                    "primary_Mrays_s": round(n / ms_p / 1e3, 1), "bounce_Mrays_s": round(live_b / ms_b / 1e3, 1), "live_bounce_rays": live_b,
+                    "work_primary": wp, "work_bounce": wb,
+                    "bvh": {"nodes": st["n_nodes"], "depth": st["max_depth"], "sah_cost": round(st["sah_cost"], 1), "build_ms": round(st["build_ms"], 1)},
+                    "nonblack_pixels": int((fb.cpu().numpy() & 0xFFFFFF != 0).sum())})
+        # parity: 64 k primary + 64 k bounce rays against the reference loop on the GPU, 4 k + 4 k against the CPU oracle
+        K = 1 << 16
+        idx = torch.from_numpy(np.sort(np.random.default_rng(7).choice(n, K, replace=False))).to(dev)
+        r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BRUTE)
+        par = {"sample_rays": 2 * K, "prim_id_mismatches_vs_gpu_brute": 0, "bit_exact_vs_gpu_brute": True, "oracle_sample": 8192, "prim_id_mismatches_vs_oracle": 0}
+        sc = oracle.Scene(tris, sph)
+        for rb, hb in ((rays, phits), (brays, bhits)):
+            s_r, s_h = rb.view(-1, 8)[idx].contiguous(), hb.view(-1, 4)[idx].contiguous()
+            bh = f32(K * 4)
+            r.trace_dev(s_r.view(-1), K, bh); torch.cuda.synchronize()
+            got, ref = s_h.cpu().numpy().view(rt.HIT).ravel(), bh.cpu().numpy().view(rt.HIT).ravel()
+            par["prim_id_mismatches_vs_gpu_brute"] += int((got["prim"] != ref["prim"]).sum())
+            par["bit_exact_vs_gpu_brute"] = bool(par["bit_exact_vs_gpu_brute"] and got.tobytes() == ref.tobytes())
+            o = oracle.trace(sc, s_r.cpu().numpy().view(rt.RAY).ravel()[:4096])
+            par["prim_id_mismatches_vs_oracle"] += int((o["prim"] != got["prim"][:4096]).sum())
+        res["parity"] = par
     out(res)
 
 
@@ -223,7 +270,7 @@ def main():
     ap.add_argument("--rays", type=int, default=64 * (1 << 20))
     a = ap.parse_args()
     for w in a.which:
-        {"c1": c1, "c2": c2, "c4": lambda: c4(a.soup, a.rays), "c5": lambda: c5(a.soup)}[w]()
+        {"c1": c1, "c2": c2, "c3": lambda: c3("sponza"), "c3b": lambda: c3("colonnade"), "c4": lambda: c4(a.soup, a.rays), "c5": lambda: c5(a.soup)}[w]()
 
 
 if __name__ == "__main__":
