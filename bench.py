@@ -114,6 +114,8 @@ def main():
     tris, sph, lights, cam = scenes.sponza_class()
     r = rt.Renderer((local_rank,))
     r.set_option(rt.OPT_TRAVERSAL, args.traversal)
+    for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # tuning sweeps only: key=value pairs of rt_set_option
+        r.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     stats = r.create_data(tris, sph, lights)
     r.update_camera(cam)
 

@@ -72,6 +72,8 @@ enum {
                                buffer + the ray-buffer kernel (+ the first-segment shade); 0 auto = 2 when the tree's SAH
                                cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for soup-like scenes whose neighbouring
                                rays walk unrelated paths, else 1 (default).  Same rays, hits and path state either way. */
+    RT_OPT_SAH_BINS = 12,   /* BVH builder: SAH bins per axis, 4..32 (default 16); takes effect at upload.  Results are unaffected. */
+    RT_OPT_SAH_TRAV = 13,   /* BVH builder: SAH cost of one interior step in hundredths of a triangle test (default 120) */
     RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for
                                measuring what it protects against only: rays that start hundreds of scene extents away
                                then lose hits the reference loop finds (tests/test_gpu_parity.py, far-origin test). */

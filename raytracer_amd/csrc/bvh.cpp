@@ -16,7 +16,7 @@
 namespace rt {
 namespace {
 
-constexpr int kBins = 16;
+constexpr int kMaxBins = 32;        // BuildParams::bins is clamped to [4, kMaxBins]
 constexpr uint32_t kSpawnThreshold = 16384;   // subtrees larger than this become pool tasks
 
 struct Task { uint32_t node, begin, end; int depth; };
@@ -104,8 +104,9 @@ struct Builder {
             for (int a = 0; a < 3; ++a) {
                 const float ext = cbox.hi[a] - cbox.lo[a];
                 if (!(ext > 0.f)) continue;
+                const int kBins = P.bins;
                 const float scale = (float)kBins / ext;
-                Aabb bb[kBins]; uint32_t bc[kBins];
+                Aabb bb[kMaxBins]; uint32_t bc[kMaxBins];
                 for (int k = 0; k < kBins; ++k) { bb[k].reset(); bc[k] = 0; }
                 for (uint32_t i = begin; i < end; ++i) {
                     const Aabb& b = pb[I[i]];
@@ -113,7 +114,7 @@ struct Builder {
                     k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
                     bb[k].grow(b); ++bc[k];
                 }
-                float ra[kBins]; uint32_t rc[kBins];
+                float ra[kMaxBins]; uint32_t rc[kMaxBins];
                 Aabb acc; acc.reset(); uint32_t cnt = 0;
                 for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); cnt += bc[k]; ra[k] = cnt ? acc.half_area() : 0.f; rc[k] = cnt; }
                 acc.reset(); cnt = 0;
@@ -131,6 +132,7 @@ struct Builder {
         uint32_t mid;
         if (best_axis >= 0) {
             const int a = best_axis;
+            const int kBins = P.bins;
             const float scale = (float)kBins / (cbox.hi[a] - cbox.lo[a]);
             const float lo = cbox.lo[a];
             const int plane = best_plane;
@@ -182,6 +184,7 @@ void build_bvh2(const Aabb* prim_boxes, uint32_t n, const BuildParams& p, BuildR
     b.pb = prim_boxes; b.P = p; b.nodes = &out.nodes; b.idx = &out.prim_index;
     if (b.P.max_leaf < 1) b.P.max_leaf = 1;
     if (b.P.max_leaf > 8) b.P.max_leaf = 8;
+    b.P.bins = std::min(std::max(b.P.bins, 4), kMaxBins);
     int nt = p.threads > 0 ? p.threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (n < 4 * kSpawnThreshold) nt = 1;
     b.parallel = nt > 1;

@@ -34,6 +34,7 @@ struct BuildParams {
     float cost_trav = 1.2f;   // SAH: one interior step
     float cost_isect = 1.0f;  // SAH: one triangle test
     int   threads = 0;        // 0 = hardware concurrency, capped at 16
+    int   bins = 16;          // SAH bins per axis (4..32)
 };
 
 struct BuildResult {

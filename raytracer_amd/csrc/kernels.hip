@@ -215,11 +215,16 @@ __device__ __forceinline__ void st_write(int* __restrict__ stk, const Spill& sp_
 template <bool COUNT, bool CAPPED = false>
 __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int node, const Slab& sl, float tmin0, float bt,
                                           int* __restrict__ stk, int& sp, Counters& c, const Spill& spill = Spill{ nullptr, 0u, 0 }) {
-    const uint4* np = reinterpret_cast<const uint4*>(nodes) + (size_t)node * 4;
+    // 32-bit byte offset from the (wave-uniform) node array: one shift instead of 64-bit address arithmetic per lane
+    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)node << 6));
     // this step touches stack slots sp-1 .. sp+2: all in LDS unless the lane is unusually deep
     const bool in_lds = !CAPPED || sp + 3 <= spill.cap;
-    int popped;
-    if (in_lds) popped = stk[(sp - 1) * kBlock]; else popped = st_read(stk, spill, sp - 1);
+    // The entry that is popped if all four children miss is read up front, always from LDS (index clamped): its latency
+    // hides under the node fetch, and the load stays a plain ds_read.  (Selecting between the LDS slot and the HBM spill
+    // column here made the compiler emit a flat load behind an address select.)  A lane so deep that the entry lives in
+    // the spill column fetches it in the rare branch at the end.
+    const int pidx = sp - 1;
+    int popped = stk[(CAPPED ? min(pidx, spill.cap - 1) : pidx) * kBlock];
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
     const uint2 q3 = *reinterpret_cast<const uint2*>(np + 3);
     const uint32_t w = q0.w;
@@ -272,6 +277,7 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         if (key[1] != miss) { st_write(stk, spill, s, ref[1]); ++s; }
     }
     const bool any = key[0] != miss;             // key[0] is the minimum: a miss there means four misses
+    if (CAPPED && !any && pidx >= spill.cap) popped = *spill_slot(spill, pidx);
     sp = any ? s : sp - 1;
     return any ? ref[0] : popped;
 }
@@ -511,7 +517,11 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         const bool need_i = node >= 0;
         if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); w_idle += __popcll(__ballot(node == kDone && pend == 0)); }
         if (need_i) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
-        if (node < 0 && node != kDone && pend == 0) { pend = node; --sp; node = CAPPED ? st_read(stk, spill, sp) : stk[sp * kBlock]; }
+        if (node < 0 && node != kDone && pend == 0) {
+            pend = node; --sp;
+            node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];             // plain ds_read; deep lanes fix it up below
+            if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
+        }
         const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);
         if (COUNT) { w_blocked += __popcll(__ballot(pend != 0 && node < 0 && node != kDone)); w_pend += __popcll(__ballot(pend != 0 && node == kDone)); }

@@ -160,6 +160,8 @@ struct rt_ctx {
     int pad_log2 = 15;          // box padding = max|coordinate| * 2^-pad_log2; the per-ray pad uses the same factor
     int ray_pad = 1;            // per-ray box pad (kernels.hip make_slab): 1 on, 0 off (measurement only: far origins then lose hits)
     int max_leaf = 4;
+    int sah_bins = 16;          // SAH bins per axis of the builder
+    int sah_trav_x100 = 120;    // SAH cost of an interior step, in hundredths of a triangle test
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
     int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
@@ -433,6 +435,8 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) try {
         case RT_OPT_MAX_LEAF:    if (v < 1 || v > 8) return fail(c, RT_E_INVALID, "RT_OPT_MAX_LEAF in [1,8]"); c->max_leaf = (int)v; return RT_OK;
         case RT_OPT_STRIP:       if (v != 0 && (v < 64 || v > (1 << 24))) return fail(c, RT_E_INVALID, "RT_OPT_STRIP: 0 or 64..2^24"); c->strip = (uint32_t)v; return RT_OK;
         case RT_OPT_REFILL:      if ((v & 0xff) < 1 || (v & 0xff) > 64 || (v >> 8) > 64) return fail(c, RT_E_INVALID, "RT_OPT_REFILL: low byte 1..64 idle lanes, bits 8.. = leaf-vote threshold 0..64"); c->refill = (int)v; return RT_OK;
+        case RT_OPT_SAH_BINS:    if (v < 4 || v > 32) return fail(c, RT_E_INVALID, "RT_OPT_SAH_BINS in [4,32]"); c->sah_bins = (int)v; return RT_OK;
+        case RT_OPT_SAH_TRAV:    if (v < 1 || v > 10000) return fail(c, RT_E_INVALID, "RT_OPT_SAH_TRAV in [1,10000] (hundredths)"); c->sah_trav_x100 = (int)v; return RT_OK;
         case RT_OPT_RAY_PAD:     if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PAD: 0 off, 1 on"); c->ray_pad = (int)v; return RT_OK;
         default: return fail(c, RT_E_INVALID, "unknown option key");
     }
@@ -455,12 +459,15 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     HostSceneParams hp;
     hp.layout = (c->traversal == 2) ? kBvh2 : kBvh4q;
     hp.max_leaf = c->max_leaf; hp.pad_log2 = c->pad_log2; hp.threads = c->bvh_threads; hp.max_depth = kStackDepth - 2;
+    hp.bins = c->sah_bins; hp.cost_trav = 0.01f * (float)c->sah_trav_x100;
     HostScene hs;
     {
         std::string err;
         const int rc = prepare_scene(tris, n_tris, tri_stride, spheres, n_spheres, sphere_stride, lights, n_lights, light_stride, hp, hs, err);
         if (rc != RT_OK) return fail(c, rc, err);
     }
+    if (hs.layout == kBvh4q && hs.n_nodes >= (1u << 26))      // the BVH4q step addresses nodes by a 32-bit byte offset
+        return fail(c, RT_E_TOO_LARGE, "more than 2^26-1 BVH4q nodes (about 200 M triangles); use RT_OPT_TRAVERSAL 2");
     const double t1 = now_ms();
 
     // replicate

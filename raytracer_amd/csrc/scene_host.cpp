@@ -46,6 +46,8 @@ int prepare_scene(const void* tris, uint32_t n_tris, uint32_t tri_stride, const 
     bp.max_leaf = p.max_leaf;
     bp.max_depth = p.max_depth;
     bp.threads = p.threads;
+    bp.bins = p.bins;
+    bp.cost_trav = p.cost_trav;
     BuildResult br;
     build_bvh2(boxes.data(), n_tris, bp, br);
     { std::vector<Aabb>().swap(boxes); }

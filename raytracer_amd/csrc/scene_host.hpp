@@ -15,6 +15,8 @@ struct HostSceneParams {
     int pad_log2 = 15;       // boxes are padded by max|coordinate| * 2^-pad_log2
     int threads = 0;
     int max_depth = 30;
+    int bins = 16;           // SAH bins per axis
+    float cost_trav = 1.2f;  // SAH cost of one interior step relative to one triangle test
     bool records = true;     // false: nodes + triangle order only (rt_bvh_build_host)
 };
 
