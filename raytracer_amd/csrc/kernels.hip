@@ -247,6 +247,9 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     const uint32_t ex = nx ? q2.w : q2.x, fx = nx ? q2.x : q2.w;      // entry / exit plane bytes, x
     const uint32_t ey = ny ? q3.x : q2.y, fy = ny ? q2.y : q3.x;
     const uint32_t ez = nz ? q3.y : q2.z, fz = nz ? q2.z : q3.y;
+#ifdef RT_PROBE_DEADPOP
+    int probe_hits_unbounded = 0;
+#endif
     uint32_t key[4];
     int ref[4] = { (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w };
     #pragma unroll
@@ -257,6 +260,9 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin0));
         const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bt));
         key[k] = (tn <= tf) ? __float_as_uint(tn) : 0xffffffffu;     // tn >= tmin0 >= 0: bits order like the value
+#ifdef RT_PROBE_DEADPOP
+        if (COUNT && tn <= fminf(fminf(tx.y, ty.y), tz.y)) ++probe_hits_unbounded;
+#endif
     }
     cswap(key[0], ref[0], key[1], ref[1]);
     cswap(key[2], ref[2], key[3], ref[3]);
@@ -277,6 +283,9 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         if (key[1] != miss) { st_write(stk, spill, s, ref[1]); ++s; }
     }
     const bool any = key[0] != miss;             // key[0] is the minimum: a miss there means four misses
+#ifdef RT_PROBE_DEADPOP
+    if (COUNT && !any && probe_hits_unbounded) ++c.spheres;   // probe build: steps in which all four children miss ONLY because of the current best t
+#endif
     if (CAPPED && !any && pidx >= spill.cap) popped = *spill_slot(spill, pidx);
     sp = any ? s : sp - 1;
     return any ? ref[0] : popped;
