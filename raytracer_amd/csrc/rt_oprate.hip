@@ -47,6 +47,27 @@ KERNEL(k_cndm2,  "v_cndmask_b32 %0, %1, %2, vcc", "v"(a), "v"(b))               
 KERNEL(k_subf,   "v_sub_f32 %0, %0, %1", "v"(a))
 KERNEL(k_xor,    "v_xor_b32 %0, %0, %1", "v"(a))
 KERNEL(k_or3,    "v_or3_b32 %0, %0, %1, %2", "v"(a), "v"(b))
+// same, with a clobber list (instructions that write or read a named SGPR pair) and a per-step instruction count
+#define KERNEL_C(NAME, ASM, CLOB, ...) \
+__global__ __launch_bounds__(256) void NAME(float* out, float a, float b) { \
+    float x[8]; \
+    for (int k = 0; k < 8; ++k) x[k] = (float)(threadIdx.x + k) * a; \
+    asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21"); \
+    for (int it = 0; it < 4096; ++it) { \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile(ASM : "+v"(x[k]) : __VA_ARGS__ : CLOB); \
+    } \
+    float s = 0.f; for (int k = 0; k < 8; ++k) s += x[k]; \
+    if (s == 12345.678f) out[0] = s; }
+KERNEL_C(k_cndm_s,   "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "memory", "v"(a))                      // mask in an SGPR pair other than vcc
+KERNEL_C(k_cndm_fma, "v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %1", "memory", "v"(a))     // 2 instructions per step
+KERNEL_C(k_cndm_3fma,"v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1", "memory", "v"(a))   // 4 per step
+KERNEL_C(k_cmp_s,    "v_cmp_lt_f32_e64 s[20:21], %0, %1", "s20", "v"(a))
+KERNEL_C(k_cmp_cndm, "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc", "vcc", "v"(a))         // the pair the compiler emits for a select
+KERNEL_C(k_ashr,     "v_ashrrev_i32 %0, 31, %0", "memory", "v"(a))
+KERNEL_C(k_maxi,     "v_max_i32 %0, %0, %1", "memory", "v"(a))
+KERNEL_C(k_or,       "v_or_b32 %0, %0, %1", "memory", "v"(a))
+KERNEL_C(k_readlane, "v_readfirstlane_b32 s20, %0", "s20", "v"(a))
+KERNEL_C(k_cndm_lit, "v_cndmask_b32_e64 %0, %0, -1, vcc", "memory", "v"(a))
 typedef void (*kfn)(float*, float, float);
 int main() {
     float* out; CHECK(hipMalloc(&out, 64));
@@ -56,7 +77,10 @@ int main() {
         {"v_cndmask_b32", k_cndm}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_cmp_lt_f32", k_cmp}, {"v_cvt_pkrtz", k_cvtpk}, {"cvt_ubyte_sdwa", k_sdwa},
         {"v_fma_mix_f32", k_fmamix}, {"v_pk_min_u16", k_pkminu}, {"v_ldexp_f32", k_ldexp}, {"v_and_or_b32", k_andor},
         {"v_lshl_or_b32", k_lshlor}, {"v_alignbit_b32", k_align}, {"v_mad_u32_u24", k_madu24}, {"v_med3_f32", k_med3}, {"v_cvt_f32_f16", k_cvtf16},
-        {"v_bfi_b32", k_bfi}, {"v_cmp_lt_u32", k_cmpu}, {"v_cndmask(no chain)", k_cndm2}, {"v_sub_f32", k_subf}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3} };
+        {"v_bfi_b32", k_bfi}, {"v_cmp_lt_u32", k_cmpu}, {"v_cndmask(no chain)", k_cndm2}, {"v_sub_f32", k_subf}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3},
+        {"v_cndmask sgpr pair", k_cndm_s}, {"cndmask+fma (x2)", k_cndm_fma}, {"cndmask+3fma (x4)", k_cndm_3fma}, {"v_cmp -> sgpr pair", k_cmp_s},
+        {"v_cmp+v_cndmask (x2)", k_cmp_cndm}, {"v_ashrrev_i32", k_ashr}, {"v_max_i32", k_maxi}, {"v_or_b32", k_or},
+        {"v_readfirstlane", k_readlane}, {"v_cndmask -1 literal", k_cndm_lit} };
     const int grid = cus * 32;
     for (auto& k : ks) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -66,7 +90,7 @@ int main() {
         CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
         double wi = (double)grid * 4 * 8.0 * 4096;
-        std::printf("%-20s %.4f instr/SIMD-cycle  (%.2f cycles per wave64 instr)\n", k.n, wi / (ms * 1e-3) / (cus * 4.0 * 2.4e9), (cus * 4.0 * 2.4e9) * (ms * 1e-3) / wi);
+        std::printf("%-20s %.4f instr/SIMD-cycle  (%.2f cycles per step of the chain; a step is one instruction unless the name says xN)\n", k.n, wi / (ms * 1e-3) / (cus * 4.0 * 2.4e9), (cus * 4.0 * 2.4e9) * (ms * 1e-3) / wi);
     }
     return 0;
 }
