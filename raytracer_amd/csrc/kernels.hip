@@ -257,8 +257,12 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         const v2f tx = __builtin_elementwise_fma((v2f){ (float)((ex >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu) }, sx2, ax2);
         const v2f ty = __builtin_elementwise_fma((v2f){ (float)((ey >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu) }, sy2, ay2);
         const v2f tz = __builtin_elementwise_fma((v2f){ (float)((ez >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu) }, sz2, az2);
-        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin0));
-        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bt));
+        // the clamps against the loop-carried tmin0 / best t as opaque instructions: written as fmaxf / fminf the compiler first
+        // canonicalises both loop-carried values (two more VALU instructions per node step); v_max_f32 / v_min_f32 return
+        // the non-NaN operand exactly like fmaxf / fminf
+        float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x), tf = fminf(fminf(tx.y, ty.y), tz.y);
+        asm("v_max_f32 %0, %1, %2" : "=v"(tn) : "v"(tn), "v"(tmin0));
+        asm("v_min_f32 %0, %1, %2" : "=v"(tf) : "v"(tf), "v"(bt));
         key[k] = (tn <= tf) ? __float_as_uint(tn) : 0xffffffffu;     // tn >= tmin0 >= 0: bits order like the value
 #ifdef RT_PROBE_DEADPOP
         if (COUNT && tn <= fminf(fminf(tx.y, ty.y), tz.y)) ++probe_hits_unbounded;
