@@ -182,6 +182,7 @@ __device__ __forceinline__ int bvh2_step(const float4* __restrict__ nodes, int n
     stk[sp * kBlock] = far;
     const bool both = h0 & h1, any = h0 | h1;
     sp += both ? 1 : (any ? 0 : -1);
+    asm volatile("" :: "v"(q3.z), "v"(q3.w));     // keeps the unused half of q3 away from the next load's destination (see bvh4q_step)
     return any ? near : popped;
 }
 
@@ -225,8 +226,7 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     // the spill column fetches it in the rare branch at the end.
     const int pidx = sp - 1;
     int popped = stk[(CAPPED ? min(pidx, spill.cap - 1) : pidx) * kBlock];
-    const uint4 q0 = np[0], q1 = np[1], q2 = np[2];
-    const uint2 q3 = *reinterpret_cast<const uint2*>(np + 3);
+    const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
     const uint32_t w = q0.w;
     if (COUNT) { ++c.nodes; c.box += w >> 24; }
     const float idx = sl.ix, idy = sl.iy, idz = sl.iz;
@@ -260,9 +260,14 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         // the clamps against the loop-carried tmin0 / best t as opaque instructions: written as fmaxf / fminf the compiler first
         // canonicalises both loop-carried values (two more VALU instructions per node step); v_max_f32 / v_min_f32 return
         // the non-NaN operand exactly like fmaxf / fminf
+#ifndef RT_NO_ASM_CLAMP
         float tn = fmaxf(fmaxf(tx.x, ty.x), tz.x), tf = fminf(fminf(tx.y, ty.y), tz.y);
         asm("v_max_f32 %0, %1, %2" : "=v"(tn) : "v"(tn), "v"(tmin0));
         asm("v_min_f32 %0, %1, %2" : "=v"(tf) : "v"(tf), "v"(bt));
+#else
+        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin0));
+        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, bt));
+#endif
         key[k] = (tn <= tf) ? __float_as_uint(tn) : 0xffffffffu;     // tn >= tmin0 >= 0: bits order like the value
 #ifdef RT_PROBE_DEADPOP
         if (COUNT && tn <= fminf(fminf(tx.y, ty.y), tz.y)) ++probe_hits_unbounded;
@@ -287,6 +292,11 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         if (key[1] != miss) { st_write(stk, spill, s, ref[1]); ++s; }
     }
     const bool any = key[0] != miss;             // key[0] is the minimum: a miss there means four misses
+    // All four quarters of the node are fetched as 16-byte loads, and the unused half of the last one is kept "live" up to
+    // here (an empty statement, no instruction): left to itself the register allocator may hand that dead half to the NEXT
+    // load of the group (seen: v[14:17] / v[16:19]), and two loads in flight with overlapping destinations cost trees
+    // that do not fit the caches 12 % (C4: 25.5 -> 28.5 ms, profiles/r02s_c4_regression.txt).
+    asm volatile("" :: "v"(q3.z), "v"(q3.w));
 #ifdef RT_PROBE_DEADPOP
     if (COUNT && !any && probe_hits_unbounded) ++c.spheres;   // probe build: steps in which all four children miss ONLY because of the current best t
 #endif
@@ -1007,34 +1017,36 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const rt_ray* __restrict__
 }
 
 // hist[block][bin] -> exclusive prefix over blocks (in place); totals[bin] = rays of the bin
-__global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t* __restrict__ totals,
-                                                        uint32_t* __restrict__ meta /* [1] += non-empty (block, bin) pairs */) {
+__global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t bins, uint32_t* __restrict__ totals,
+                                                        uint32_t* __restrict__ meta /* [1] += non-empty (block, bin) pairs; null = do not count */) {
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= kBins) return;
+    if (b >= bins) return;
     uint32_t run = 0, pairs = 0;
     for (uint32_t k0 = 0; k0 < n_blocks; k0 += 16) {         // 16 independent loads in flight, then the serial prefix
         uint32_t v[16];
         #pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) v[j] = (k0 + j < n_blocks) ? hist[(size_t)(k0 + j) * kBins + b] : 0u;
+        for (uint32_t j = 0; j < 16; ++j) v[j] = (k0 + j < n_blocks) ? hist[(size_t)(k0 + j) * bins + b] : 0u;
         #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
-            if (k0 + j < n_blocks) hist[(size_t)(k0 + j) * kBins + b] = run;
+            if (k0 + j < n_blocks) hist[(size_t)(k0 + j) * bins + b] = run;
             run += v[j];
             pairs += v[j] != 0u;
         }
     }
     totals[b] = run;
-    if (pairs) atomicAdd(&meta[1], pairs);
+    if (meta && pairs) atomicAdd(&meta[1], pairs);
 }
 
 // totals[bin] -> start of the bin in the permutation (exclusive scan, one block)
-__global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ totals, uint32_t* __restrict__ meta, uint64_t n, uint32_t min_run) {
-    if (threadIdx.x == 0) meta[0] = (min_run == 0u || n < (uint64_t)min_run * meta[1]) ? 1u : 0u;   // permute?
+// decide: 1 = this launch takes the permute / keep decision (meta[0]) from the pair count; 0 = leaves it as it is
+__global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ totals, uint32_t bins, uint32_t* __restrict__ meta, uint64_t n,
+                                                     uint32_t min_run, int decide) {
+    if (decide && threadIdx.x == 0) meta[0] = (min_run == 0u || n < (uint64_t)min_run * meta[1]) ? 1u : 0u;   // permute?
     __shared__ uint32_t part[kBlock];
-    constexpr uint32_t per = (kBins + kBlock - 1) / kBlock;
+    const uint32_t per = (bins + kBlock - 1) / kBlock;
     const uint32_t lo = threadIdx.x * per;
     uint32_t sum = 0;
-    for (uint32_t k = 0; k < per; ++k) if (lo + k < kBins) sum += totals[lo + k];
+    for (uint32_t k = 0; k < per; ++k) if (lo + k < bins) sum += totals[lo + k];
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1043,7 +1055,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ tota
     }
     __syncthreads();
     uint32_t run = part[threadIdx.x];
-    for (uint32_t k = 0; k < per; ++k) if (lo + k < kBins) { const uint32_t v = totals[lo + k]; totals[lo + k] = run; run += v; }
+    for (uint32_t k = 0; k < per; ++k) if (lo + k < bins) { const uint32_t v = totals[lo + k]; totals[lo + k] = run; run += v; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block, BinGrid g,
@@ -1055,7 +1067,128 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const rt_ray* __restrict
     for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) cur[b] = starts[b] + row[b];
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) perm[atomicAdd(&cur[ray_bin(rays, i, g)], 1u)] = (uint32_t)i;
+    // four rays per thread and round: the loads of a round are in flight together (one ray per round left the kernel
+    // waiting for one load after the other: 1.5 ms for 64 Mi rays)
+    for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * kBlock) {
+        uint32_t b[4];
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t i = i0 + (uint64_t)k * kBlock; b[k] = i < hi ? ray_bin(rays, i, g) : 0u; }
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t i = i0 + (uint64_t)k * kBlock; if (i < hi) perm[atomicAdd(&cur[b[k]], 1u)] = (uint32_t)i; }
+    }
+}
+
+// ---- two-level variant for large buffers --------------------------------------------------------------------
+// The one-level scatter keeps blocks x 4097 write streams open at once (16-entry runs that fill over a block's whole
+// loop): far more lines than the L2s hold, so they are evicted half-filled and written several times (measured: 4.4 GB
+// of HBM traffic for 2.3 GB of algorithmic bytes on 64 Mi rays, 1.5 ms).  Here the sort goes by the upper 7 bits of
+// the bin first (65 streams per block, runs of ~1,000 entries) and by the whole bin second, on an array that is
+// grouped by the upper bits already, so a block of the second level meets ~100 bins and writes runs of ~600 entries.
+// The bin of every ray is computed once (16 bits per ray) instead of re-reading the 32-byte rays.
+__global__ __launch_bounds__(kBlock) void k_bin2_count(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block, BinGrid g,
+                                                       uint16_t* __restrict__ keys, uint32_t* __restrict__ hist_hi /* [block][kBinsHi] */,
+                                                       uint32_t* __restrict__ meta) {
+    __shared__ uint32_t h[kBins];
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) h[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const uint32_t b = ray_bin(rays, i, g);
+        keys[i] = (uint16_t)b;
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    // non-empty (block, bin) pairs -> the coherence decision of k_bin_scan; upper-level histogram row
+    uint32_t pairs = 0;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) pairs += h[b] != 0u;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pairs += __shfl_down(pairs, off, 64);
+    if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(&meta[1], pairs);
+    if (threadIdx.x < kBinsHi) {
+        uint32_t sum = 0;
+        const uint32_t first = threadIdx.x << kBinLoBits, last = min(first + (1u << kBinLoBits), kBins);
+        for (uint32_t b = first; b < last; ++b) sum += h[b];
+        hist_hi[(size_t)blockIdx.x * kBinsHi + threadIdx.x] = sum;
+    }
+}
+
+// The second-level kernels read 2 to 6 bytes per ray: with one ray per thread and round a CU would keep ~2 KB in flight and
+// crawl at a tenth of the HBM rate (measured: 0.74 ms for 0.5 GB), so a thread takes 8 consecutive entries per round
+// (one 16-byte load of keys, two of indices).  per_block is a multiple of 8 (launch_bin), so the loads stay aligned.
+__device__ __forceinline__ void load_keys8(const uint16_t* __restrict__ keys, uint64_t i, uint64_t hi, uint32_t k[8]) {
+    if (i + 8 <= hi) {
+        const uint4 q = *reinterpret_cast<const uint4*>(keys + i);
+        k[0] = q.x & 0xffffu; k[1] = q.x >> 16; k[2] = q.y & 0xffffu; k[3] = q.y >> 16;
+        k[4] = q.z & 0xffffu; k[5] = q.z >> 16; k[6] = q.w & 0xffffu; k[7] = q.w >> 16;
+    } else {
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = i + j < hi ? keys[i + j] : 0u;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin2_scatter_hi(const uint16_t* __restrict__ keys, uint64_t n, uint64_t per_block,
+                                                            const uint32_t* __restrict__ hist_hi, const uint32_t* __restrict__ starts_hi,
+                                                            const uint32_t* __restrict__ meta, uint32_t* __restrict__ tmp_idx,
+                                                            uint16_t* __restrict__ tmp_key) {
+    __shared__ uint32_t cur[kBinsHi];
+    if (meta[0] == 0u) return;                                               // coherent input: keep its order
+    if (threadIdx.x < kBinsHi) cur[threadIdx.x] = starts_hi[threadIdx.x] + hist_hi[(size_t)blockIdx.x * kBinsHi + threadIdx.x];
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    for (uint64_t i = lo + (uint64_t)threadIdx.x * 8; i < hi; i += 8 * kBlock) {
+        uint32_t k[8];
+        load_keys8(keys, i, hi, k);
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i + j < hi) {
+                const uint32_t dst = atomicAdd(&cur[k[j] >> kBinLoBits], 1u);
+                tmp_idx[dst] = (uint32_t)(i + j);
+                tmp_key[dst] = (uint16_t)k[j];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin2_count_keys(const uint16_t* __restrict__ tmp_key, uint64_t n, uint64_t per_block,
+                                                            const uint32_t* __restrict__ meta, uint32_t* __restrict__ hist /* [block][kBins] */) {
+    __shared__ uint32_t h[kBins];
+    if (meta[0] == 0u) return;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) h[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    for (uint64_t i = lo + (uint64_t)threadIdx.x * 8; i < hi; i += 8 * kBlock) {
+        uint32_t k[8];
+        load_keys8(tmp_key, i, hi, k);
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) if (i + j < hi) atomicAdd(&h[k[j]], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * kBins;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) row[b] = h[b];
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin2_scatter_keys(const uint16_t* __restrict__ tmp_key, const uint32_t* __restrict__ tmp_idx, uint64_t n,
+                                                              uint64_t per_block, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ starts,
+                                                              const uint32_t* __restrict__ meta, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t cur[kBins];
+    if (meta[0] == 0u) return;
+    const uint32_t* row = hist + (size_t)blockIdx.x * kBins;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) cur[b] = starts[b] + row[b];
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    for (uint64_t i = lo + (uint64_t)threadIdx.x * 8; i < hi; i += 8 * kBlock) {
+        uint32_t k[8], id[8];
+        load_keys8(tmp_key, i, hi, k);
+        if (i + 8 <= hi) {
+            const uint4 a = *reinterpret_cast<const uint4*>(tmp_idx + i), c = *reinterpret_cast<const uint4*>(tmp_idx + i + 4);
+            id[0] = a.x; id[1] = a.y; id[2] = a.z; id[3] = a.w; id[4] = c.x; id[5] = c.y; id[6] = c.z; id[7] = c.w;
+        } else {
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) id[j] = i + j < hi ? tmp_idx[i + j] : 0u;
+        }
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) if (i + j < hi) perm[atomicAdd(&cur[k[j]], 1u)] = id[j];
+    }
 }
 
 // LDS for the per-lane stacks: sentinel + one entry per BVH level (+1 spare), [entry][thread]
@@ -1080,7 +1213,7 @@ inline int num_cus() {                        // of the current device (cached p
 int device_cus() { return num_cus(); }
 
 hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st,
-                      uint32_t max_blocks) {
+                      uint32_t max_blocks, bool two_level) {
     if (n == 0) return hipSuccess;
     if (n >= (1ull << 32) || max_blocks == 0) return hipErrorInvalidValue;
     uint32_t* perm = d_scratch;
@@ -1088,13 +1221,33 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
     uint32_t* totals = hist + (size_t)max_blocks * kBins;
     uint32_t* meta = totals + kBins;                 // [0] permute flag, [1] non-empty (block, bin) pairs
     const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(max_blocks, (n + 4095) / 4096);
-    const uint64_t per_block = (n + n_blocks - 1) / n_blocks;
+    const uint64_t per_block = (((n + n_blocks - 1) / n_blocks) + 7) & ~7ull;      // multiple of 8: aligned 16-byte loads in the second level
     hipError_t e = hipMemsetAsync(meta, 0, 4 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bin_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist);
-    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, totals, meta);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, meta, n, min_run);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, meta, perm);
+    if (!two_level) {
+        hipLaunchKernelGGL(k_bin_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist);
+        hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, meta);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 1);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, meta, perm);
+        return hipGetLastError();
+    }
+    // two levels (see k_bin2_count): behind meta come the index array of the first level and the two 16-bit key arrays
+    // (each array starts on a 16-byte boundary of the 256-byte-aligned scratch: the second level loads 16 bytes at a time)
+    auto align4 = [](uint64_t words) { return (words + 3) & ~3ull; };
+    const uint64_t off_idx = align4(n + (uint64_t)max_blocks * kBins + kBins + 4), off_keys = align4(off_idx + n), off_tmp = align4(off_keys + (n + 1) / 2);
+    uint32_t* tmp_idx = d_scratch + off_idx;
+    uint16_t* keys = reinterpret_cast<uint16_t*>(d_scratch + off_keys);
+    uint16_t* tmp_key = reinterpret_cast<uint16_t*>(d_scratch + off_tmp);
+    uint32_t* hist_hi = hist;                                                // rows of kBinsHi words; the full-width rows reuse the area afterwards
+    uint32_t* totals_hi = totals;
+    hipLaunchKernelGGL(k_bin2_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, keys, hist_hi, meta);
+    hipLaunchKernelGGL(k_bin_columns, dim3(1), dim3(kBlock), 0, st, hist_hi, n_blocks, kBinsHi, totals_hi, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals_hi, kBinsHi, meta, n, min_run, 1);
+    hipLaunchKernelGGL(k_bin2_scatter_hi, dim3(n_blocks), dim3(kBlock), 0, st, keys, n, per_block, hist_hi, totals_hi, meta, tmp_idx, tmp_key);
+    hipLaunchKernelGGL(k_bin2_count_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, n, per_block, meta, hist);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 0);
+    hipLaunchKernelGGL(k_bin2_scatter_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, tmp_idx, n, per_block, hist, totals, meta, perm);
     return hipGetLastError();
 }
 

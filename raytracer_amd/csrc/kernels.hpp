@@ -37,15 +37,22 @@ constexpr uint32_t kBins = kBinCells + 1;
 constexpr uint32_t kBinBlocksMax = 1024;
 struct BinGrid { float lox, loy, loz, sx, sy, sz; };        // cell = clamp((o - lo) * s, 0, 15)
 // scratch words (uint32) that launch_bin needs for n rays: the permutation + per-block histograms
-inline uint64_t bin_scratch_words(uint64_t n, uint32_t max_blocks = kBinBlocksMax) { return n + (uint64_t)max_blocks * kBins + kBins + 4; }
+// two_level (launch_bin): + the first level's index array (n words) and two arrays of 16-bit bins (n/2 words each, rounded up)
+constexpr uint32_t kBinLoBits = 6;                                   // second-level digit; the first level sorts by bin >> 6
+constexpr uint32_t kBinsHi = ((kBins - 1) >> kBinLoBits) + 1;       // 65
+constexpr uint64_t kBinTwoLevelMin = 1ull << 22;                     // buffers from this size on take the two-level sort
+inline uint64_t bin_scratch_words(uint64_t n, uint32_t max_blocks = kBinBlocksMax, bool two_level = false) {
+    return n + (uint64_t)max_blocks * kBins + kBins + 4 + (two_level ? n + 2 * ((n + 1) / 2) + 16 : 0);      // + alignment slack
+}
 // word 0 behind the bin totals: 1 if the permutation is to be used (see launch_bin), 0 if the input was coherent already
 inline const uint32_t* bin_flag(const uint32_t* d_scratch, uint64_t n, uint32_t max_blocks = kBinBlocksMax) { return d_scratch + n + (uint64_t)max_blocks * kBins + kBins; }
 // d_scratch[0 .. n) receives the permutation (ray indices grouped by bin); n must be < 2^32
 // min_run: the rays are only permuted when a (64 Ki-ray block, cell) pair holds fewer than min_run rays on average,
 // i.e. when the buffer is not grouped by origin already (0 = always permute).  The decision is taken on the device.
 // max_blocks: histogram rows the scratch was sized for (bin_scratch_words with the same value)
+// two_level: sort by the upper bits of the bin first (large buffers: see k_bin2_count); needs bin_scratch_words(n, max_blocks, true)
 hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32_t* d_scratch, uint32_t min_run, hipStream_t st,
-                      uint32_t max_blocks = kBinBlocksMax);
+                      uint32_t max_blocks = kBinBlocksMax, bool two_level = false);
 
 // Scratch of one strip-kernel launch (the caller owns it and keeps launches that share it ordered):
 //   work       kWorkWords u64: 8 chunk cursors + the mask of exhausted eighths, kCursorStride apart (zeroed by launch_trace)

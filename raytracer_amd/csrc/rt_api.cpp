@@ -237,7 +237,8 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
     const uint32_t* perm = nullptr;
     hipError_t e;
     if (bin) {
-        const uint64_t words = bin_scratch_words(n);
+        const bool two_level = n >= kBinTwoLevelMin;
+        const uint64_t words = bin_scratch_words(n, kBinBlocksMax, two_level);
         if (words > r.bin_cap) {
             if (r.d_bin) (void)hipFree(r.d_bin);          // hipFree waits for the device: no launch still reads it
             r.d_bin = nullptr; r.bin_cap = 0;
@@ -247,7 +248,7 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         }
         if ((e = scratch_acquire(r, kEvBin, st)) != hipSuccess) return e;
         // auto: permute only buffers that are not grouped by origin already (camera-ordered bounce rays are)
-        e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, c->binning == 1 ? 0u : kBinMinRun, st);
+        e = launch_bin(d_rays, n, c->bin_grid, r.d_bin, c->binning == 1 ? 0u : kBinMinRun, st, kBinBlocksMax, two_level);
         if (e != hipSuccess) return e;
         perm = r.d_bin;
     }

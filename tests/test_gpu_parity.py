@@ -291,6 +291,33 @@ def test_ray_binning_changes_the_order_not_the_answer(renderer, torch_dev):
     assert renderer.trace(rays).tobytes() == out[0][0].tobytes()
 
 
+def test_two_level_binning_of_large_buffers(renderer, torch_dev):
+    """Buffers of 2^22 rays and more are binned in two levels (upper bits of the cell first).  Same contract as above:
+    the order changes, no record does -- for shuffled rays and for a buffer sorted by x (very uneven first-level runs)."""
+    n = (1 << 22) + 1237
+    st, rays = scenes.soup(30000, half_extent=0.02), scenes.random_rays(n)
+    rays["o"][::9] = rays["o"][::9] * 4 - 2
+    rays["tmax"][::6] = 0.0
+    rays["tmax"][1::17] = 0.03
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+    renderer.create_data(st)
+    for label, r_np in (("shuffled", rays), ("sorted by x", rays[np.argsort(rays["o"][:, 0], kind="stable")])):
+        d_rays = to_dev(torch_dev, r_np)
+        out = {}
+        for binning in (0, 1):
+            renderer.set_option(rt.OPT_RAY_BINNING, binning)
+            hits = dev_buf(torch_dev, n, 16)
+            renderer.trace_dev(d_rays, n, hits)
+            torch_dev.cuda.synchronize()
+            out[binning] = to_np(hits, rt.HIT).copy()
+        assert out[0].tobytes() == out[1].tobytes(), label
+        dead = ~(r_np["tmax"] > r_np["tmin"])
+        assert (out[1]["prim"][dead] == rt.MISS).all() and (out[1]["prim"] != rt.MISS).any()
+        idx = np.sort(np.random.default_rng(4).choice(n, 2048, replace=False))
+        assert_parity(out[1][idx], oracle.trace(oracle.Scene(st), r_np[idx]), f"two-level binned sample vs oracle ({label})")
+    renderer.set_option(rt.OPT_RAY_BINNING, 2)
+
+
 def test_capped_lds_stack_with_spill_changes_nothing(renderer, torch_dev):
     """RT_OPT_LDS_STACK: the ray-buffer kernel keeps only the first entries of a lane's stack in LDS and spills deeper ones
     to HBM.  Caps 2 and 3 force nearly every push through the spill path; every cap must give the uncapped records."""
