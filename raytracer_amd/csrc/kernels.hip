@@ -436,6 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
 #else
 #define RT_STRIP_ATTR
 #endif
+constexpr int kSecondStepLanes = 36;      // lanes on interior nodes from which a round takes a second interior step
 template <int MODE, bool ANY, bool COUNT, bool CAPPED>
 __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth,
@@ -544,6 +545,19 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             pend = node; --sp;
             node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];             // plain ds_read; deep lanes fix it up below
             if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
+        }
+        // A second interior step in the same round when most of the wave still stands on interior nodes: the round's fixed
+        // work (refill vote, leaf parking, triangle-block vote, result write: ~65 VALU instructions against 114 for the node
+        // step) is then spread over two steps.  Below the threshold the step would run half empty and cost more than it saves
+        // (thresholds 24..44 measured alike, a third step is slower: profiles/r02u_two_steps.txt).  Bounce 3.67 -> 3.57 ms.
+        if ((int)__popcll(__ballot(node >= 0)) >= kSecondStepLanes) {
+            if (COUNT) { w_i += __popcll(__ballot(node >= 0)); }
+            if (node >= 0) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
+            if (node < 0 && node != kDone && pend == 0) {
+                pend = node; --sp;
+                node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];
+                if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
+            }
         }
         const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);

@@ -33,7 +33,7 @@ def find_overlaps(asm_text):
         if op.startswith("s_waitcnt") and "vmcnt" in s or op.startswith(("s_cbranch", "s_branch", "s_endpgm")):
             group = []
             continue
-        if op.startswith(("global_load", "flat_load", "buffer_load", "scratch_load")):
+        if op.startswith(("global_load", "flat_load", "buffer_load")):      # (scratch reloads are the register allocator's own)
             d = re.match(r"^\S+\s+v\[(\d+):(\d+)\]|^\S+\s+v(\d+)", s)
             if not d: continue
             regs = set(range(int(d.group(1)), int(d.group(2)) + 1)) if d.group(1) else {int(d.group(3))}
