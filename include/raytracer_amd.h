@@ -59,7 +59,7 @@ enum {
     RT_OPT_MAX_LEAF = 5,    /* triangles per BVH leaf, 1..8 (default 4); takes effect at upload */
     RT_OPT_STRIP = 6,       /* ray-buffer kernel: rays per chunk a persistent wave draws (default 256); 0 = one ray per lane, no refill */
     RT_OPT_REFILL = 7,      /* ray-buffer kernel: low byte = idle lanes that trigger a refill (default 16),
-                               bits 8.. = lanes holding a parked leaf before the triangle block runs (default 24) */
+                               bits 8.. = lanes holding a parked leaf before the triangle block runs (default 12) */
     RT_OPT_RAY_BINNING = 8, /* ray-buffer kernel: hand rays out grouped by origin cell (16^3 Morton grid over the scene,
                                dead rays last): 0 off, 1 on, 2 auto = when nodes + triangles exceed 48 MB and the buffer
                                holds >= 2^18 rays (default).  Output order and values are unaffected.  Uses per-slot

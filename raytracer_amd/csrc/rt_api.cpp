@@ -163,7 +163,7 @@ struct rt_ctx {
     int sah_bins = 16;          // SAH bins per axis of the builder
     int sah_trav_x100 = 120;    // SAH cost of an interior step, in hundredths of a triangle test
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
-    int refill = 16 | (24 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold
+    int refill = 16 | (12 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold (profiles/r02v_sweep_refill.txt)
     int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
     int primary_path = 0;       // primary rays: 0 auto, 1 tile kernel (k_primary), 2 ray generation + ray-buffer kernel
     int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
