@@ -215,7 +215,9 @@ def main():
             dist.destroy_process_group()
         return
     import hashlib
-    frame_sha = hashlib.sha256(frame.reshape(-1)[: W * H].cpu().numpy().tobytes()).hexdigest()
+    frame_np = frame.reshape(-1)[: W * H].cpu().numpy()
+    frame_sha = hashlib.sha256(frame_np.tobytes()).hexdigest()
+    lit_pixels = int((frame_np.view("uint32") & 0xFFFFFF != 0).sum())       # the hash says something only if the frame is not black
 
     value = rays_per_step * args.steps / elapsed / 1e6
     n_real_local = c_primary["rays"]                     # live rays this rank traces per generation
@@ -266,6 +268,7 @@ def main():
                            "depth": stats["max_depth"], "node_bytes": stats["node_bytes"],
                            "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
         "frame_sha256": frame_sha,       # RGBA8 framebuffer: identical for every N (decomposition-invariant RNG keys)
+        "frame_lit_pixels": lit_pixels,
         "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
                   "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
                   "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0")},
