@@ -67,11 +67,15 @@ enum {
     RT_OPT_LDS_STACK = 9,   /* ray-buffer kernel, BVH4q nodes: traversal-stack entries per lane kept in LDS (default 20, 2..64);
                                deeper entries spill to a per-slot area in HBM, which lets 8 waves per SIMD run instead of
                                3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected. */
-    RT_OPT_PRIMARY = 10,    /* primary rays: 1 = tile kernel (8x8 pixels per wave, generation fused with traversal and, in
-                               rt_primary_shade_stripes_dev, with the first shading segment); 2 = ray generation into a
-                               buffer + the ray-buffer kernel (+ the first-segment shade); 0 auto = 2 when the tree's SAH
-                               cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for soup-like scenes whose neighbouring
-                               rays walk unrelated paths, else 1 (default).  Same rays, hits and path state either way. */
+    RT_OPT_PRIMARY = 10,    /* primary rays.  1 = tile kernel, one ray per lane with its own traversal stack (generation fused
+                               with traversal and, in rt_primary_shade_stripes_dev, with the first shading segment);
+                               3 = the same kernel with PACKET traversal: the 64 rays of a wave (a 4x4 .. 8x8 pixel tile)
+                               walk the tree together, node by node, from an fp32 copy of the BVH4q nodes fetched with
+                               scalar loads (128 B per node more in HBM; set before rt_scene_upload);
+                               2 = ray generation into a buffer + the ray-buffer kernel (+ the first-segment shade);
+                               0 auto (default) = 2 when the tree's SAH cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for
+                               soup-like scenes whose neighbouring rays walk unrelated paths, else 3 (1 for BVH2 trees).
+                               Same rays, hits and path state in every case. */
     RT_OPT_SAH_BINS = 12,   /* BVH builder: SAH bins per axis, 4..32 (default 16); takes effect at upload.  Results are unaffected. */
     RT_OPT_SAH_TRAV = 13,   /* BVH builder: SAH cost of one interior step in hundredths of a triangle test (default 120) */
     RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for

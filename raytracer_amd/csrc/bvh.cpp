@@ -328,8 +328,8 @@ int gather4(const BuildResult& b, uint32_t i, uint32_t out[4]) {
 
 }  // namespace
 
-void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
-    out.nodes.clear(); out.tri_order.clear();
+void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out, bool want_wide) {
+    out.nodes.clear(); out.tri_order.clear(); out.wide.clear();
     out.n_nodes = 0; out.n_leaves = b.n_leaves; out.depth = 0; out.stack_need = 0;
     if (b.nodes.empty()) return;
 
@@ -381,6 +381,7 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
 
     out.n_nodes = (uint32_t)wide.size();
     out.nodes.assign((size_t)out.n_nodes * 16, 0u);
+    if (want_wide) out.wide.assign((size_t)out.n_nodes * 32, 0u);
     for (uint32_t wi = 0; wi < out.n_nodes; ++wi) {
         const Wide& w = wide[wi];
         uint32_t* q = &out.nodes[(size_t)wi * 16];
@@ -419,11 +420,22 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out) {
                 q[hi_word] |= h8 << (8 * k);
             }
         }
+        if (want_wide) {
+            uint32_t* wq = &out.wide[(size_t)wi * 32];
+            wq[4] = (uint32_t)w.n;
+            const float far = 3.0e38f;        // empty slot: a point at "infinity", missed by arithmetic whatever the ray's signs
+            for (int k = 0; k < 4; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    std::memcpy(&wq[8 + 6 * k + 2 * a], k < w.n ? &lo[k][a] : &far, 4);
+                    std::memcpy(&wq[8 + 6 * k + 2 * a + 1], k < w.n ? &hi[k][a] : &far, 4);
+                }
+        }
         std::memcpy(&q[0], &org[0], 4); std::memcpy(&q[1], &org[1], 4); std::memcpy(&q[2], &org[2], 4);
         q[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16) | ((uint32_t)w.n << 24);
         for (int k = 0; k < 4; ++k) {
             int32_t r = (k < w.n) ? ref[w.child[k]] : leaf_ref(0, 1);
             std::memcpy(&q[4 + k], &r, 4);
+            if (want_wide) std::memcpy(&out.wide[(size_t)wi * 32 + k], &r, 4);
             if (k >= w.n) {                                   // empty slot: inverted box (lo 255, hi 0) never hits
                 for (int a = 0; a < 3; ++a) q[8 + a] |= 0xffu << (8 * k);
             }

@@ -78,9 +78,14 @@ struct FlatBvh4q {
     std::vector<uint32_t> tri_order;
     uint32_t n_nodes = 0, n_leaves = 0, depth = 0;
     uint32_t stack_need = 0;          // exact bound on traversal-stack entries (excluding the sentinel)
+    // The same nodes with fp32 planes for the packet traversal of the tile kernel (a wave walks ONE node at a time and
+    // fetches it with scalar loads, so nothing has to be decoded per lane), 32 words = 128 B per node:
+    //   [0..3] child references, [4] number of children, [5..7] 0,
+    //   [8 + 6k ..] child k: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z  (the PADDED box, not the quantised one; empty slots: every plane at +3e38)
+    std::vector<uint32_t> wide;       // filled only when flatten_bvh4q is asked to (want_wide)
 };
 
-void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out);
+void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out, bool want_wide = false);
 
 // exact bound on the BVH2 traversal stack (entries pushed along the worst root-to-leaf path)
 uint32_t bvh2_stack_need(const BuildResult& b);

@@ -362,6 +362,100 @@ __device__ __forceinline__ void trace_ray(const DevScene& s, f3 o, f3 d, float t
     else                trace_bvh<MODE, ANY, COUNT>(s, o, d, tmin, tmax, b, c, stk);
 }
 
+// ---- packet traversal (tile kernel, BVH4q trees with the fp32 "wide" node copy: bvh.hpp) ---------------------------
+// The 64 rays of a wave of the tile kernel are a 4x4 .. 8x8 pixel tile from one origin: they visit almost the same
+// nodes.  Here the WAVE walks the tree: one node at a time for all lanes, the traversal stack and every decision in
+// scalar registers, nodes and triangles fetched with scalar loads (no per-lane node fetch, no byte decoding, no
+// per-lane sort, no LDS).  Per node and lane that leaves the slab arithmetic: 12 packed fma and the min/max of four
+// children.  A child is entered when ANY lane's ray meets it (ballot), children are ordered by the entry distance of the
+// first lane that hits them, and every lane tests every triangle of a leaf the wave visits.  Each lane therefore tests
+// a superset of what it would test alone, against its own best t; by the order-independent replacement rule
+// (consider) the closest hit of every ray is the one the per-lane walk and the reference loop find, bit for bit.
+// The stack is one VGPR used as a 64-entry array (lane i = entry i, v_writelane / v_readlane with a scalar index).
+// v_writelane_b32 with a scalar value and a scalar lane index (this compiler has the readlane builtin only); the lane
+// select goes through m0, because the two scalar operands may not both come from different SGPRs on gfx9-class VALU
+// (m0 is reserved by the compiler and cannot be named as a clobber, so it is saved and restored around the instruction)
+__device__ __forceinline__ int write_lane(int vec, int value, int lane) {
+    int saved;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+        : "+v"(vec), "=&s"(saved) : "s"(value), "s"(lane));
+    return vec;
+}
+__device__ __forceinline__ void cswap_s(uint32_t& ka, int& ra, uint32_t& kb, int& rb) {
+    if (kb < ka) { const uint32_t k = ka; ka = kb; kb = k; const int r = ra; ra = rb; rb = r; }
+}
+// v_min / v_max as opaque instructions: like fminf / fmaxf they return the non-NaN operand, but the compiler does not
+// put a canonicalising v_max(x, x) in front of every operand it cannot prove quiet (six per child in this loop)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_packet(const DevScene& s, f3 o, f3 d, float tmin, bool active, Best& b, Counters& c) {
+    if (s.n_nodes == 0) return;
+    const uint4* __restrict__ wide = reinterpret_cast<const uint4*>(s.wide);
+    const float4* __restrict__ tris = s.tris;
+    const Slab sl = make_slab<kBvh2>(o, d, s.ray_pad);
+    // (lo, hi) plane constants: the box grown by the per-ray pad on both sides (as in bvh2_step)
+    const v2f ix2 = (v2f){ sl.ix, sl.ix }, iy2 = (v2f){ sl.iy, sl.iy }, iz2 = (v2f){ sl.iz, sl.iz };
+    const v2f cx = (v2f){ sl.ex, __fmaf_rn(sl.m2, sl.ix, sl.ex) }, cy = (v2f){ sl.ey, __fmaf_rn(sl.m2, sl.iy, sl.ey) },
+              cz = (v2f){ sl.ez, __fmaf_rn(sl.m2, sl.iz, sl.ez) };
+    const float tmin0 = fmaxf(tmin, 0.0f);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    const uint32_t miss = 0xffffffffu;
+    int stack = 0;                      // lane i holds stack entry i
+    int sp = 0, node = 0;               // wave-uniform
+    for (;;) {
+        if (node >= 0) {
+            // the whole 128-byte node in one go (uniform address: scalar loads), then straight-line code: no child is
+            // skipped by a branch -- empty slots carry planes at +3e38 and miss by arithmetic
+            const uint4* np = wide + (size_t)(uint32_t)node * 8;
+            const uint4 w0 = np[0], w1 = np[1], p0 = np[2], p1 = np[3], p2 = np[4], p3 = np[5], p4 = np[6], p5 = np[7];
+            if (COUNT && active) { ++c.nodes; c.box += w1.x; }
+            const uint32_t pl[24] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w,
+                                      p3.x, p3.y, p3.z, p3.w, p4.x, p4.y, p4.z, p4.w, p5.x, p5.y, p5.z, p5.w };
+            int ref[4] = { (int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w };
+            uint32_t key[4];
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v2f tx = __builtin_elementwise_fma((v2f){ __uint_as_float(pl[6 * k]), __uint_as_float(pl[6 * k + 1]) }, ix2, cx);
+                const v2f ty = __builtin_elementwise_fma((v2f){ __uint_as_float(pl[6 * k + 2]), __uint_as_float(pl[6 * k + 3]) }, iy2, cy);
+                const v2f tz = __builtin_elementwise_fma((v2f){ __uint_as_float(pl[6 * k + 4]), __uint_as_float(pl[6 * k + 5]) }, iz2, cz);
+                const float tn = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), tmin0);
+                const float tf = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), b.t);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(tn <= tf) & act;
+                // entry distance of the first lane that meets the child (tn >= 0: its bits order like the value)
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(tn), (int)__builtin_ctzll(m | (1ull << 63)));
+                key[k] = m ? first : miss;
+            }
+            cswap_s(key[0], ref[0], key[1], ref[1]);
+            cswap_s(key[2], ref[2], key[3], ref[3]);
+            cswap_s(key[0], ref[0], key[2], ref[2]);
+            cswap_s(key[1], ref[1], key[3], ref[3]);
+            cswap_s(key[1], ref[1], key[2], ref[2]);
+            if (key[3] != miss) { stack = write_lane(stack, ref[3], sp); ++sp; }
+            if (key[2] != miss) { stack = write_lane(stack, ref[2], sp); ++sp; }
+            if (key[1] != miss) { stack = write_lane(stack, ref[1], sp); ++sp; }
+            if (key[0] != miss) { node = ref[0]; continue; }
+        } else {
+            const uint32_t r = ~(uint32_t)node;                               // (first << 3) | (count - 1)
+            const uint32_t first = r >> 3, cnt = (r & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4* tp = tris + (size_t)(first + k) * 3;            // uniform address: scalar loads
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                float t, u, v;
+                if (active && tri_hit(o, d, mk(q0.x, q0.y, q0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), t, u, v))
+                    consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
+                if (COUNT && active) ++c.tris;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = __builtin_amdgcn_readlane(stack, sp);
+    }
+}
+
 // b.key == 0 can also be sphere 0 (key 0): a hit is recognised by t < tmax instead.
 __device__ __forceinline__ float4 pack_hit(const Best& b, float tmax) {
     bool hit = b.t < tmax;
@@ -745,7 +839,7 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
 // the primary ray and its hit never travel through HBM (rays_out / hits become optional outputs), and the
 // path-state buffers are written once instead of filled, read and written.
 struct ShadeOut { float4* thr; float4* rad; float4* next; uint32_t seed; };
-template <int MODE, bool COUNT, bool SHADE>
+template <int MODE, bool COUNT, bool SHADE, bool PACKET = false>
 __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
                                                     uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
                                                     uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
@@ -764,8 +858,11 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
     const uint32_t y = y0 + (yl / stripe_h) * stripe_h * stripe_step + (yl % stripe_h);
     const bool active = wave < n_waves && x < w && yl < rows && y < h;
     Counters c = { 0, 0, 0, 0 };
+    f3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 0.0f);
+    const float tmin = 0.0f, tmax = 1e20f;                            // :266
+    const uint32_t key = (y * w + x) * spp + smp;                     // RNG key: full-image ray index
+    Best b;
     if (active) {
-        const uint32_t key = (y * w + x) * spp + smp;                 // RNG key: full-image ray index
         float uvx = ((float)x + 0.5f) / (float)w;                     // vert.glsl:9-12 pixel centre
         float uvy = ((float)y + 0.5f) / (float)h;
         float ndcx = __fmaf_rn(uvx, 2.0f, -1.0f), ndcy = __fmaf_rn(uvy, 2.0f, -1.0f);   // :91
@@ -774,16 +871,23 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
             ndcy += (rand01(key, 1u, seed) - 0.5f) * (2.0f / 1080.0f);
         }
         float a = ndcx * cam.half_w, bb = ndcy * cam.half_h;          // :114-115
-        f3 d = mk(__fmaf_rn(bb, cam.ux, a * cam.rx) + cam.fx, __fmaf_rn(bb, cam.uy, a * cam.ry) + cam.fy,
-                  __fmaf_rn(bb, cam.uz, a * cam.rz) + cam.fz);
+        d = mk(__fmaf_rn(bb, cam.ux, a * cam.rx) + cam.fx, __fmaf_rn(bb, cam.uy, a * cam.ry) + cam.fy,
+               __fmaf_rn(bb, cam.uz, a * cam.rz) + cam.fz);
         d = norm3(d);                                                 // :113
         d = norm3(d);                                                 // :120
-        f3 o = mk(cam.px, cam.py, cam.pz);
-        const float tmin = 0.0f, tmax = 1e20f;                        // :266
-        Best b;
-        int* stk = stack + (MODE == kBvh2 || MODE == kBvh4q ? threadIdx.x : 0);
+        o = mk(cam.px, cam.py, cam.pz);
+    }
+    int* stk = stack + (MODE == kBvh2 || MODE == kBvh4q ? threadIdx.x : 0);
+    if (PACKET) {
+        // the whole wave walks the tree together (trace_packet); lanes without a ray only follow
+        b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;               // frag.glsl:266
+        if (active) spheres_pass<COUNT>(s, o, d, tmin, b, c);
+        trace_packet<COUNT>(s, o, d, tmin, active, b, c);
+    } else if (active) {
         if (MODE != kNone) trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stk);
         else { b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u; }       // ray generation only
+    }
+    if (active) {
         const size_t r = ((size_t)yl * w + x) * spp + smp;
         const float4 r0 = make_float4(o.x, o.y, o.z, tmin), r1 = make_float4(d.x, d.y, d.z, tmax), hit = pack_hit(b, tmax);
         if (rays_out) { rays_out[2 * r] = r0; rays_out[2 * r + 1] = r1; }
@@ -1386,6 +1490,15 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
 #define RT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_primary<M, C, S>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                               jitter, tiles_x, n_waves, rays, hits, d_counters, so, quad)
 #define RT_LAUNCH_M(M) do { if (shade) RT_LAUNCH(M, false, true); else if (count) RT_LAUNCH(M, true, false); else RT_LAUNCH(M, false, false); } while (0)
+    // packet traversal: BVH4q trees with the wide node copy whose stack fits the 64 lanes of the stack register.  The
+    // per-lane LDS stack is then only needed by the shadow rays of the fused shading stage (scenes with lights).
+    if (mode == kBvh4q && s.wide && s.stack_depth + 2 <= 64) {
+        const size_t lds = (shade && s.n_lights) ? stack_bytes(s, kBvh4q) : 0;
+#define RT_LAUNCH_P(C, S) hipLaunchKernelGGL((k_primary<kBvh4q, C, S, true>), g, b, lds, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
+                                              jitter, tiles_x, n_waves, rays, hits, d_counters, so, quad)
+        if (shade) RT_LAUNCH_P(false, true); else if (count) RT_LAUNCH_P(true, false); else RT_LAUNCH_P(false, false);
+#undef RT_LAUNCH_P
+    } else
     if (mode == kNone) hipLaunchKernelGGL((k_primary<kNone, false, false>), g, b, 0, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays, nullptr, d_counters, so, quad);
     else if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH

@@ -15,6 +15,7 @@ struct DevScene {
     const float4* materials; // 3 x float4 per distinct material: (albedo, strength) (emission, roughness) (metallic,0,0,0)
     const uint32_t* sphere_mat;  // material id per sphere; triangles keep theirs in normals[3*i].w
     const float4* lights;    // 2 x float4 per light: (position, intensity) (colour, 0)
+    const uint32_t* wide;    // BVH4q only: 32 words per node with fp32 planes (bvh.hpp), null = no packet traversal
     uint32_t n_nodes, n_tris, n_spheres, stack_depth, n_lights;
     float ray_pad;           // per-ray box pad = ray_pad * max|origin coordinate| (kernels.hip make_slab); 2^-pad_log2, 0 = off
 };

@@ -113,6 +113,7 @@ struct Replica {
     float4* d_materials = nullptr;
     float4* d_sphere_mat = nullptr;   // uint32 ids, allocated through the float4 helper
     float4* d_lights = nullptr;
+    float4* d_wide = nullptr;         // fp32 copy of the BVH4q nodes for the packet traversal (null when not built)
     // scratch for rt_render
     void* d_render = nullptr; size_t render_cap = 0;
     unsigned long long* d_counters = nullptr;      // kCountersPad words of counters, then kSpillSlots cursor sets
@@ -184,6 +185,8 @@ struct rt_ctx {
         s.nodes = r.d_nodes; s.tris = r.d_tris; s.normals = r.d_normals; s.spheres = r.d_spheres;
         s.materials = r.d_materials; s.sphere_mat = reinterpret_cast<const uint32_t*>(r.d_sphere_mat); s.lights = r.d_lights;
         s.n_lights = stats.n_lights;
+        // packet traversal of the tile kernel: RT_OPT_PRIMARY 3 forces it, 0 (auto) takes it when the wide nodes exist
+        s.wide = (primary_path == 0 || primary_path == 3) ? reinterpret_cast<const uint32_t*>(r.d_wide) : nullptr;
         s.n_nodes = stats.n_nodes; s.n_tris = stats.n_tris; s.n_spheres = stats.n_spheres;
         s.stack_depth = stack_need;
         s.ray_pad = ray_pad ? std::ldexp(1.0f, -pad_log2) : 0.0f;
@@ -215,6 +218,8 @@ void free_scene(Replica& r) {
     if (r.d_materials) (void)hipFree(r.d_materials);
     if (r.d_sphere_mat) (void)hipFree(r.d_sphere_mat);
     if (r.d_lights) (void)hipFree(r.d_lights);
+    if (r.d_wide) (void)hipFree(r.d_wide);
+    r.d_wide = nullptr;
     r.d_nodes = r.d_tris = r.d_normals = r.d_spheres = r.d_materials = r.d_sphere_mat = r.d_lights = nullptr;
 }
 
@@ -290,7 +295,7 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
 constexpr float kPrimaryBufferSah = 250.0f;
 bool primary_via_buffer(const rt_ctx* c) {
     const int mode = c->mode();
-    if (mode == kBrute || c->strip < 64 || c->counters || c->primary_path == 1) return false;
+    if (mode == kBrute || c->strip < 64 || c->counters || c->primary_path == 1 || c->primary_path == 3) return false;
     if (c->primary_path == 2) return true;
     return c->stats.sah_cost > kPrimaryBufferSah;
 }
@@ -429,7 +434,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) try {
         case RT_OPT_BVH_THREADS: if (v < 0 || v > 256) return fail(c, RT_E_INVALID, "RT_OPT_BVH_THREADS out of range"); c->bvh_threads = (int)v; return RT_OK;
         case RT_OPT_COUNTERS:    c->counters = v ? 1 : 0; return RT_OK;
         case RT_OPT_LDS_STACK:   if (v != 0 && (v < 2 || v > 64)) return fail(c, RT_E_INVALID, "RT_OPT_LDS_STACK: 0 or 2..64 entries"); c->lds_stack = (int)v; return RT_OK;
-        case RT_OPT_PRIMARY:     if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_PRIMARY: 0 auto, 1 tile kernel, 2 ray-buffer kernel"); c->primary_path = (int)v; return RT_OK;
+        case RT_OPT_PRIMARY:     if (v < 0 || v > 3) return fail(c, RT_E_INVALID, "RT_OPT_PRIMARY: 0 auto, 1 tile kernel (one ray per lane), 2 ray-buffer kernel, 3 tile kernel (packet traversal)"); c->primary_path = (int)v; return RT_OK;
         case RT_OPT_RAY_BINNING: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_RAY_BINNING: 0 off, 1 on, 2 auto"); c->binning = (int)v; return RT_OK;
         // 2^-4 .. 2^-20: below 2^-20 (16 ulp) the conservative-traversal argument of DESIGN.md no longer holds
         case RT_OPT_PAD_LOG2:    if (v < 4 || v > 20) return fail(c, RT_E_INVALID, "RT_OPT_PAD_LOG2 in [4,20]"); c->pad_log2 = (int)v; return RT_OK;
@@ -460,6 +465,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     HostSceneParams hp;
     hp.layout = (c->traversal == 2) ? kBvh2 : kBvh4q;
     hp.max_leaf = c->max_leaf; hp.pad_log2 = c->pad_log2; hp.threads = c->bvh_threads; hp.max_depth = kStackDepth - 2;
+    hp.wide = c->primary_path != 1 && c->primary_path != 2;      // the tile kernel's packet traversal wants fp32 nodes
     hp.bins = c->sah_bins; hp.cost_trav = 0.01f * (float)c->sah_trav_x100;
     HostScene hs;
     {
@@ -491,6 +497,9 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
         RT_HIP(c, up(&r.d_materials, hs.mats.data(), hs.mats.size() * 4));
         RT_HIP(c, up(&r.d_sphere_mat, hs.sphere_mat.data(), hs.sphere_mat.size() * 4));
         RT_HIP(c, up(&r.d_lights, hs.lights8.data(), hs.lights8.size() * 4));
+        // (soup-like trees send their primary rays through the ray-buffer kernel: no wide copy in HBM for them)
+        if (!hs.wide.empty() && (c->primary_path == 3 || hs.sah_cost <= kPrimaryBufferSah))
+            RT_HIP(c, up(&r.d_wide, hs.wide.data(), hs.wide.size() * 4));
     }
     const double t2 = now_ms();
 
@@ -511,7 +520,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     st.stack_entries = hs.stack_need + 2;
     st.sah_cost = hs.sah_cost;
     st.build_ms = (float)(t1 - t0); st.upload_ms = (float)(t2 - t1);
-    st.device_bytes = (uint64_t)hs.nodes.size() * 4 + (uint64_t)hs.tri48.size() * 4 + (uint64_t)hs.nrm48.size() * 4 + (uint64_t)hs.sph.size() * 4;
+    st.device_bytes = (uint64_t)hs.nodes.size() * 4 + (uint64_t)hs.tri48.size() * 4 + (uint64_t)hs.nrm48.size() * 4 + (uint64_t)hs.sph.size() * 4 + (uint64_t)hs.wide.size() * 4;
     c->has_scene = true;
     return RT_OK;
 } RT_ABI_CATCH(c)

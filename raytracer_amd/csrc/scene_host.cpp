@@ -58,11 +58,11 @@ int prepare_scene(const void* tris, uint32_t n_tris, uint32_t tri_stride, const 
     const float pad = n_tris ? std::ldexp(std::max(maxabs, 1e-30f), -p.pad_log2) : 0.f;
     if (layout == 3) {
         FlatBvh4q f4;
-        flatten_bvh4q(br, pad, f4);
+        flatten_bvh4q(br, pad, f4, p.wide && p.records);
         if (f4.stack_need + 2 > 64) {
             layout = 2;                         // pathological tree: its 4-wide stack would not fit 64 KB of LDS
         } else {
-            out.nodes.swap(f4.nodes); out.tri_order.swap(f4.tri_order);
+            out.nodes.swap(f4.nodes); out.tri_order.swap(f4.tri_order); out.wide.swap(f4.wide);
             out.n_nodes = f4.n_nodes; out.n_leaves = f4.n_leaves; out.depth = f4.depth; out.stack_need = f4.stack_need;
         }
     }

@@ -17,11 +17,13 @@ struct HostSceneParams {
     int max_depth = 30;
     int bins = 16;           // SAH bins per axis
     float cost_trav = 1.2f;  // SAH cost of one interior step relative to one triangle test
+    bool wide = false;       // also flatten the fp32 "wide" copy of a BVH4q tree (packet traversal of the tile kernel)
     bool records = true;     // false: nodes + triangle order only (rt_bvh_build_host)
 };
 
 struct HostScene {
     std::vector<uint32_t> nodes;       // 16 words per node, layout `layout`
+    std::vector<uint32_t> wide;        // 32 words per node (bvh.hpp FlatBvh4q::wide) or empty
     std::vector<uint32_t> tri_order;   // tri_order[k] = original index of the triangle stored at slot k
     std::vector<float> tri48;          // 12 floats per triangle in leaf order: (v0, bits id) (e1, 0) (e2, 0)
     std::vector<float> nrm48;          // 12 floats per triangle in ORIGINAL order: n0, n1, n2; material id in n0.w

@@ -644,7 +644,7 @@ def test_primary_through_the_ray_buffer_kernel_equals_the_tile_kernel(renderer, 
         n = p.padded_rows * w * spp
         f = lambda k: torch.full((n * k,), 3.0, dtype=torch.float32, device="cuda")
         got = {}
-        for path in (1, 2):
+        for path in (1, 2, 3):
             renderer.set_option(rt.OPT_PRIMARY, path)
             ra, hits, ra2, hits2, thr, rad, nxt, thr3, rad3, nxt3 = f(8), f(4), f(8), f(4), f(4), f(4), f(8), f(4), f(4), f(8)
             renderer.trace_primary_stripes_dev(w, h, p.y0, p.padded_rows, sh, world, hits, ra, spp=spp, seed=seed, jitter=True, stream=s)
@@ -658,12 +658,13 @@ def test_primary_through_the_ray_buffer_kernel_equals_the_tile_kernel(renderer, 
             got[path] = [t.clone() for t in (ra, hits, ra2, hits2, thr, rad, nxt, thr3, rad3, nxt3, hits4)]
         names = ("rays", "hits", "rays (fused call)", "hits (fused call)", "throughput", "radiance", "next rays",
                  "throughput (no copies)", "radiance (no copies)", "next rays (no copies)", "hits (no ray copy)")
-        for a, b, what in zip(got[1], got[2], names):
-            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (world, rank, what)
+        for other in (2, 3):      # 2 = ray generation + ray-buffer kernel, 3 = packet traversal in the tile kernel
+            for a, b, what in zip(got[1], got[other], names):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (world, rank, other, what)
         assert torch.equal(got[2][0].view(torch.int32), got[2][2].view(torch.int32)) and torch.equal(got[2][1].view(torch.int32), got[2][10].view(torch.int32))
     renderer.set_option(rt.OPT_PRIMARY, 0)
     with pytest.raises(RuntimeError):
-        renderer.set_option(rt.OPT_PRIMARY, 3)
+        renderer.set_option(rt.OPT_PRIMARY, 4)
 
 
 def test_rt_render_matches_oracle_frame():
