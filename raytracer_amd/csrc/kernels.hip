@@ -391,12 +391,13 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-template <bool COUNT>
-__device__ __forceinline__ void trace_packet(const DevScene& s, f3 o, f3 d, float tmin, bool active, Best& b, Counters& c) {
-    if (s.n_nodes == 0) return;
+// OCT: bit a set = every ray of the wave points down axis a (its entry plane is the hi plane), known at compile time, so
+// entry and exit t of an axis are simply the two halves of one packed fma; OCT = 8: signs differ inside the wave (tiles on
+// the camera's axis lines), entry / exit by min / max (six more instructions per child).
+template <bool COUNT, int OCT>
+__device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float tmin, bool active, const Slab& sl, Best& b, Counters& c) {
     const uint4* __restrict__ wide = reinterpret_cast<const uint4*>(s.wide);
     const float4* __restrict__ tris = s.tris;
-    const Slab sl = make_slab<kBvh2>(o, d, s.ray_pad);
     // (lo, hi) plane constants: the box grown by the per-ray pad on both sides (as in bvh2_step)
     const v2f ix2 = (v2f){ sl.ix, sl.ix }, iy2 = (v2f){ sl.iy, sl.iy }, iz2 = (v2f){ sl.iz, sl.iz };
     const v2f cx = (v2f){ sl.ex, __fmaf_rn(sl.m2, sl.ix, sl.ex) }, cy = (v2f){ sl.ey, __fmaf_rn(sl.m2, sl.iy, sl.ey) },
@@ -422,8 +423,14 @@ __device__ __forceinline__ void trace_packet(const DevScene& s, f3 o, f3 d, floa
                 const v2f tx = __builtin_elementwise_fma((v2f){ __uint_as_float(pl[6 * k]), __uint_as_float(pl[6 * k + 1]) }, ix2, cx);
                 const v2f ty = __builtin_elementwise_fma((v2f){ __uint_as_float(pl[6 * k + 2]), __uint_as_float(pl[6 * k + 3]) }, iy2, cy);
                 const v2f tz = __builtin_elementwise_fma((v2f){ __uint_as_float(pl[6 * k + 4]), __uint_as_float(pl[6 * k + 5]) }, iz2, cz);
-                const float tn = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), tmin0);
-                const float tf = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), b.t);
+                float tn, tf;
+                if (OCT < 8) {
+                    tn = vmax(vmax3((OCT & 1) ? tx.y : tx.x, (OCT & 2) ? ty.y : ty.x, (OCT & 4) ? tz.y : tz.x), tmin0);
+                    tf = vmin(vmin3((OCT & 1) ? tx.x : tx.y, (OCT & 2) ? ty.x : ty.y, (OCT & 4) ? tz.x : tz.y), b.t);
+                } else {
+                    tn = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), tmin0);
+                    tf = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), b.t);
+                }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(tn <= tf) & act;
                 // entry distance of the first lane that meets the child (tn >= 0: its bits order like the value)
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(tn), (int)__builtin_ctzll(m | (1ull << 63)));
@@ -453,6 +460,29 @@ __device__ __forceinline__ void trace_packet(const DevScene& s, f3 o, f3 d, floa
         if (sp == 0) break;
         --sp;
         node = __builtin_amdgcn_readlane(stack, sp);
+    }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_packet(const DevScene& s, f3 o, f3 d, float tmin, bool active, Best& b, Counters& c) {
+    if (s.n_nodes == 0) return;
+    const Slab sl = make_slab<kBvh2>(o, d, s.ray_pad);
+    // direction signs of the wave's rays (of the reciprocals the slabs use): uniform on all three axes for nearly every tile
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    const unsigned long long nx = __builtin_amdgcn_ballot_w64(sl.ix < 0.0f) & act, ny = __builtin_amdgcn_ballot_w64(sl.iy < 0.0f) & act,
+                             nz = __builtin_amdgcn_ballot_w64(sl.iz < 0.0f) & act;
+    const bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
+    const int oct = uniform ? ((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0)) : 8;
+    switch (oct) {
+        case 0: packet_walk<COUNT, 0>(s, o, d, tmin, active, sl, b, c); break;
+        case 1: packet_walk<COUNT, 1>(s, o, d, tmin, active, sl, b, c); break;
+        case 2: packet_walk<COUNT, 2>(s, o, d, tmin, active, sl, b, c); break;
+        case 3: packet_walk<COUNT, 3>(s, o, d, tmin, active, sl, b, c); break;
+        case 4: packet_walk<COUNT, 4>(s, o, d, tmin, active, sl, b, c); break;
+        case 5: packet_walk<COUNT, 5>(s, o, d, tmin, active, sl, b, c); break;
+        case 6: packet_walk<COUNT, 6>(s, o, d, tmin, active, sl, b, c); break;
+        case 7: packet_walk<COUNT, 7>(s, o, d, tmin, active, sl, b, c); break;
+        default: packet_walk<COUNT, 8>(s, o, d, tmin, active, sl, b, c); break;
     }
 }
 
