@@ -118,6 +118,10 @@ def main():
         r.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     stats = r.create_data(tris, sph, lights)
     r.update_camera(cam)
+    # which primary kernel the library picks for this tree (include/raytracer_amd.h, RT_OPT_PRIMARY)
+    forced = {kv.split("=")[0]: kv.split("=")[1] for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(","))}.get("10", "0")
+    primary_kernel = ({"1": "k_primary", "2": "ray generation + k_trace_strip", "3": "k_primary_packet"}.get(forced) or
+                      ("ray generation + k_trace_strip" if stats["sah_cost"] > 250 else "k_primary_packet" if args.traversal == 3 else "k_primary"))
 
     plan = rd.stripe_plan(H, world, rank, STRIPE)
     n_local = plan.padded_rows * W * SPP                 # local ray slots (padding rows are dead rays)
@@ -273,8 +277,12 @@ def main():
                   "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
                   "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0")},
         # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints
-        "launch": {"dynamic_lds_bytes_per_block": {"k_primary": stats["stack_entries"] * 1024,
+        # (the packet form of the tile kernel keeps its stack in a register: no LDS unless the scene has lights, whose
+        # shadow rays walk per lane)
+        "launch": {"dynamic_lds_bytes_per_block": {"k_primary_packet": stats["stack_entries"] * 1024 if len(lights) else 0,
+                                                   "k_primary": stats["stack_entries"] * 1024,
                                                    "k_trace_strip": min(stats["stack_entries"], 20) * 1024},
+                   "primary_kernel": primary_kernel,
                    "stack_entries": stats["stack_entries"], "lds_stack_option": 20},
         "roofline": roofline, "roofline_hbm": roofline_hbm,
         "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_shade_ms": round(ms_primary, 4),

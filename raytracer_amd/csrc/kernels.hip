@@ -869,12 +869,11 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
 // the primary ray and its hit never travel through HBM (rays_out / hits become optional outputs), and the
 // path-state buffers are written once instead of filled, read and written.
 struct ShadeOut { float4* thr; float4* rad; float4* next; uint32_t seed; };
-template <int MODE, bool COUNT, bool SHADE, bool PACKET = false>
-__global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
-                                                    uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
-                                                    uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
-                                                    float4* __restrict__ hits, unsigned long long* counters, ShadeOut so, int quad) {
-    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
+template <int MODE, bool COUNT, bool SHADE, bool PACKET>
+__device__ __forceinline__ void primary_body(int* stack /* dynamic LDS */, const DevScene& s, const DevCamera& cam, uint32_t w, uint32_t h, uint32_t y0,
+                                             uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
+                                             uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
+                                             float4* __restrict__ hits, unsigned long long* counters, const ShadeOut& so, int quad) {
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     // lane -> (pixel, sample): a wave takes S = 4, 2 or 1 samples (the largest that divides spp; quad = log2 S) of a
@@ -945,6 +944,29 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
         }
     }
     flush_counters<COUNT>(c, active, counters);
+}
+
+template <int MODE, bool COUNT, bool SHADE>
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
+                                                    uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
+                                                    uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
+                                                    float4* __restrict__ hits, unsigned long long* counters, ShadeOut so, int quad) {
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
+    primary_body<MODE, COUNT, SHADE, false>(stack, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays_out, hits, counters, so, quad);
+}
+
+// The packet form (trace_packet).  A wave waits for one scalar node fetch after the other, so the kernel lives on waves
+// per SIMD: the traversal loops need 40 VGPRs, the fused shading segment 108.  Asked for 8 waves (64 VGPRs) the allocator
+// spills 33 registers, all of them in the shading code that runs once per ray, none in the traversal loops: primary +
+// segment 0 2.12 -> 1.81 ms (5 waves 1.98, 6 waves 1.92; profiles/r02z_packet.txt).
+template <bool COUNT, bool SHADE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_primary_packet(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
+                      uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
+                      uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
+                      float4* __restrict__ hits, unsigned long long* counters, ShadeOut so, int quad) {
+    extern __shared__ int stack[];      // only the shadow rays of the fused shading stage use it (scenes with lights)
+    primary_body<kBvh4q, COUNT, SHADE, true>(stack, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays_out, hits, counters, so, quad);
 }
 
 // frag.glsl:321-330 for one light, fused: shadow-ray build + closest-hit + lit test.
@@ -1524,7 +1546,7 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
     // per-lane LDS stack is then only needed by the shadow rays of the fused shading stage (scenes with lights).
     if (mode == kBvh4q && s.wide && s.stack_depth + 2 <= 64) {
         const size_t lds = (shade && s.n_lights) ? stack_bytes(s, kBvh4q) : 0;
-#define RT_LAUNCH_P(C, S) hipLaunchKernelGGL((k_primary<kBvh4q, C, S, true>), g, b, lds, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
+#define RT_LAUNCH_P(C, S) hipLaunchKernelGGL((k_primary_packet<C, S>), g, b, lds, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                               jitter, tiles_x, n_waves, rays, hits, d_counters, so, quad)
         if (shade) RT_LAUNCH_P(false, true); else if (count) RT_LAUNCH_P(true, false); else RT_LAUNCH_P(false, false);
 #undef RT_LAUNCH_P
