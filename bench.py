@@ -277,9 +277,8 @@ def main():
                   "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
                   "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0")},
         # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints
-        # (the packet form of the tile kernel keeps its stack in a register: no LDS unless the scene has lights, whose
-        # shadow rays walk per lane)
-        "launch": {"dynamic_lds_bytes_per_block": {"k_primary_packet": stats["stack_entries"] * 1024 if len(lights) else 0,
+        # (the packet form of the tile kernel keeps its stack in a register: no LDS)
+        "launch": {"dynamic_lds_bytes_per_block": {"k_primary_packet": 0,
                                                    "k_primary": stats["stack_entries"] * 1024,
                                                    "k_trace_strip": min(stats["stack_entries"], 20) * 1024},
                    "primary_kernel": primary_kernel,

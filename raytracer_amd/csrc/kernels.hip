@@ -818,13 +818,18 @@ __device__ __forceinline__ f3 hemisphere(f3 N, float xi1, float xi2) {          
 // One segment of the path loop (frag.glsl:310-354) for one path: T, C in/out; returns false when the path ends
 // here (miss or dead ray: T and C are left as they are).  With want_next the bounce ray (o, dir) is produced
 // and T updated (:340-350); key = index of the path in the FULL frame (decomposition-invariant RNG).
-template <int MODE>
+// PACKET (tile kernel with packet traversal only): the function is called by ALL lanes of the wave, `valid` says which
+// of them carry a path; the shadow rays of a wave -- neighbouring surface points, one light -- then walk the tree together
+// (trace_packet) instead of lane by lane with stacks in LDS.  Same closest hits, so the same lit / unlit decisions.
+template <int MODE, bool PACKET = false>
 __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r1, float4 hit, f3& T, f3& C, uint32_t key,
-                                          uint32_t seed, bool want_next, int* stk, f3& o, f3& dir) {
-    f3 P, N;
+                                          uint32_t seed, bool want_next, int* stk, f3& o, f3& dir, bool valid = true) {
+    f3 P = mk(0.0f, 0.0f, 0.0f), N = mk(0.0f, 0.0f, 1.0f);
     f3 d = mk(r1.x, r1.y, r1.z);
-    if (!(r1.w > r0.w) || !hit_point(s, mk(r0.x, r0.y, r0.z), d, hit, P, N)) return false;   // :351-353 the path ends
-    const uint32_t prim = __float_as_uint(hit.w);
+    const bool ok = valid && (r1.w > r0.w) && hit_point(s, mk(r0.x, r0.y, r0.z), d, hit, P, N);
+    if (!PACKET && !ok) return false;                                               // :351-353 the path ends
+    if (PACKET && s.n_lights == 0 && !ok) return false;                             // no wave-wide work ahead
+    const uint32_t prim = ok ? __float_as_uint(hit.w) : 0u;
     const uint32_t mid = (prim & RT_SPHERE_BIT) ? s.sphere_mat[prim & ~RT_SPHERE_BIT]
                                                 : __float_as_uint(s.normals[(size_t)prim * 3].w);
     const Mat m = load_mat(s, mid);
@@ -840,7 +845,14 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
         f3 so = madd3(0.001f, N, P);
         Best b; Counters c = { 0, 0, 0, 0 };
         const float tmax = 1e20f;
-        trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stk);
+        if (PACKET) {
+            b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
+            if (ok) spheres_pass<false>(s, so, L, 0.0f, b, c);
+            trace_packet<false>(s, so, L, 0.0f, ok, b, c);
+            if (!ok) continue;
+        } else {
+            trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stk);
+        }
         bool lit = true;
         if (b.t < tmax) {
             f3 dl = sub3(madd3(b.t, L, so), P);
@@ -854,6 +866,7 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
                    __fmaf_rn((T.z * B.z) * (l1.z * ia), NdotL, C.z));                // :335-336
         }
     }
+    if (PACKET && !ok) return false;
     if (!want_next) return true;           // last segment of a path: only its radiance is still needed
     dir = hemisphere(N, rand01(key, 2u, seed), rand01(key, 3u, seed));              // :340
     o = madd3(0.001f, N, P);                                                        // :342
@@ -916,14 +929,21 @@ __device__ __forceinline__ void primary_body(int* stack /* dynamic LDS */, const
         if (MODE != kNone) trace_ray<MODE, false, COUNT>(s, o, d, tmin, tmax, b, c, stk);
         else { b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u; }       // ray generation only
     }
+    // segment 0 of the path loop.  In the packet form the shadow rays of the wave walk the tree together, so every lane
+    // makes the call (lanes without a ray or without a hit only follow: `valid`).
+    f3 T = mk(1.0f, 1.0f, 1.0f), C = mk(0.0f, 0.0f, 0.0f), no = mk(0.0f, 0.0f, 0.0f), nd = mk(0.0f, 0.0f, 0.0f);   // :306-307
+    bool go = false;
+    if (SHADE && PACKET) {
+        const float4 r0 = make_float4(o.x, o.y, o.z, tmin), r1 = make_float4(d.x, d.y, d.z, tmax), hit = pack_hit(b, tmax);
+        go = shade_one<MODE, true>(s, r0, r1, hit, T, C, key, so.seed, so.next != nullptr, stk, no, nd, active);
+    }
     if (active) {
         const size_t r = ((size_t)yl * w + x) * spp + smp;
         const float4 r0 = make_float4(o.x, o.y, o.z, tmin), r1 = make_float4(d.x, d.y, d.z, tmax), hit = pack_hit(b, tmax);
         if (rays_out) { rays_out[2 * r] = r0; rays_out[2 * r + 1] = r1; }
         if (hits) hits[r] = hit;
         if (SHADE) {
-            f3 T = mk(1.0f, 1.0f, 1.0f), C = mk(0.0f, 0.0f, 0.0f), no, nd;             // :306-307
-            const bool go = shade_one<MODE>(s, r0, r1, hit, T, C, key, so.seed, so.next != nullptr, stk, no, nd);
+            if (!PACKET) go = shade_one<MODE>(s, r0, r1, hit, T, C, key, so.seed, so.next != nullptr, stk, no, nd);
             so.thr[r] = make_float4(T.x, T.y, T.z, 0.0f);
             so.rad[r] = make_float4(C.x, C.y, C.z, 0.0f);
             if (so.next) {
@@ -965,8 +985,7 @@ void k_primary_packet(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_
                       uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
                       uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
                       float4* __restrict__ hits, unsigned long long* counters, ShadeOut so, int quad) {
-    extern __shared__ int stack[];      // only the shadow rays of the fused shading stage use it (scenes with lights)
-    primary_body<kBvh4q, COUNT, SHADE, true>(stack, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays_out, hits, counters, so, quad);
+    primary_body<kBvh4q, COUNT, SHADE, true>(nullptr, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays_out, hits, counters, so, quad);
 }
 
 // frag.glsl:321-330 for one light, fused: shadow-ray build + closest-hit + lit test.
@@ -1542,10 +1561,9 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
 #define RT_LAUNCH(M, C, S) hipLaunchKernelGGL((k_primary<M, C, S>), g, b, stack_bytes(s, M), st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                               jitter, tiles_x, n_waves, rays, hits, d_counters, so, quad)
 #define RT_LAUNCH_M(M) do { if (shade) RT_LAUNCH(M, false, true); else if (count) RT_LAUNCH(M, true, false); else RT_LAUNCH(M, false, false); } while (0)
-    // packet traversal: BVH4q trees with the wide node copy whose stack fits the 64 lanes of the stack register.  The
-    // per-lane LDS stack is then only needed by the shadow rays of the fused shading stage (scenes with lights).
+    // packet traversal: BVH4q trees with the wide node copy whose stack fits the 64 lanes of the stack register
     if (mode == kBvh4q && s.wide && s.stack_depth + 2 <= 64) {
-        const size_t lds = (shade && s.n_lights) ? stack_bytes(s, kBvh4q) : 0;
+        const size_t lds = 0;          // the shadow rays of the fused shading stage walk as packets too: no per-lane stacks
 #define RT_LAUNCH_P(C, S) hipLaunchKernelGGL((k_primary_packet<C, S>), g, b, lds, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, \
                                               jitter, tiles_x, n_waves, rays, hits, d_counters, so, quad)
         if (shade) RT_LAUNCH_P(false, true); else if (count) RT_LAUNCH_P(true, false); else RT_LAUNCH_P(false, false);
