@@ -121,7 +121,7 @@ def main():
     # which primary kernel the library picks for this tree (include/raytracer_amd.h, RT_OPT_PRIMARY)
     forced = {kv.split("=")[0]: kv.split("=")[1] for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(","))}.get("10", "0")
     primary_kernel = ({"1": "k_primary", "2": "ray generation + k_trace_strip", "3": "k_primary_packet"}.get(forced) or
-                      ("ray generation + k_trace_strip" if stats["sah_cost"] > 250 else "k_primary_packet" if args.traversal == 3 else "k_primary"))
+                      ("k_primary_packet" if args.traversal == 3 else "ray generation + k_trace_strip" if stats["sah_cost"] > 250 else "k_primary"))
 
     plan = rd.stripe_plan(H, world, rank, STRIPE)
     n_local = plan.padded_rows * W * SPP                 # local ray slots (padding rows are dead rays)

@@ -73,8 +73,9 @@ enum {
                                walk the tree together, node by node, from an fp32 copy of the BVH4q nodes fetched with
                                scalar loads (128 B per node more in HBM; set before rt_scene_upload);
                                2 = ray generation into a buffer + the ray-buffer kernel (+ the first-segment shade);
-                               0 auto (default) = 2 when the tree's SAH cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for
-                               soup-like scenes whose neighbouring rays walk unrelated paths, else 3 (1 for BVH2 trees).
+                               0 auto (default) = 3 for BVH4q trees (ahead on every scene measured, tessellated or soup);
+                               for BVH2 trees 2 when the tree's SAH cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for
+                               soup-like scenes whose neighbouring rays walk unrelated paths, else 1.
                                Same rays, hits and path state in every case. */
     RT_OPT_SAH_BINS = 12,   /* BVH builder: SAH bins per axis, 4..32 (default 16); takes effect at upload.  Results are unaffected. */
     RT_OPT_SAH_TRAV = 13,   /* BVH builder: SAH cost of one interior step in hundredths of a triangle test (default 120) */

@@ -171,6 +171,7 @@ struct rt_ctx {
     BinGrid bin_grid{};         // 16^3 grid over the triangle bounds of the uploaded scene
     // scene
     bool has_scene = false, has_camera = false;
+    bool has_wide = false;      // the fp32 node copy for packet traversal was uploaded with the scene
     rt_scene_stats stats{};
     DevCamera cam{};
     uint32_t stack_need = 0;    // traversal-stack entries the uploaded tree can need
@@ -286,17 +287,19 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
     return hipSuccess;
 }
 
-// Primary rays of a "hard" tree go through the ray-buffer kernel (ray generation -> k_trace_strip).  What decides is
-// not the size of the scene but how long and how divergent traversals are, which the tree's SAH cost predicts: on
-// random soups (SAH cost 300..1800) neighbouring pixels walk unrelated paths and the tile kernel, which walks each ray
-// of a wave to the end, loses (10 M triangles: 50 ms against 17 ms); on tessellated surfaces (SAH cost 8..72, up to
-// 8 M triangles measured) neighbouring rays stay together and the tile kernel is ahead (C3: 2.7 against 3.7 ms).
-// Crossover measured at SAH cost ~250 (scripts/primary_threshold*.py).  Same rays, same hits either way.
+// Which kernel takes the primary rays.  With the wide node copy uploaded (BVH4q trees, unless RT_OPT_PRIMARY is 1 or 2)
+// it is the packet form of the tile kernel: ahead of both others on every scene measured, tessellated surfaces up to 8.4 M
+// triangles (2.2 ms against 6.2 / 5.1 ms) and random soups up to 10 M (3.6 ms against 13.0 / 6.1 ms; scripts/primary_threshold*.py,
+// profiles/r03b_*).  Without it (BVH2 trees, RT_OPT_PRIMARY 1) the round-1 rule holds: a "hard" tree, recognised by its SAH
+// cost, sends its primary rays through ray generation + the ray-buffer kernel, because the one-ray-per-lane tile kernel walks
+// every ray of a wave to the end (10 M-triangle soup: 50 ms against 17 ms); crossover at SAH cost ~250.  Same rays and hits
+// in every case.
 constexpr float kPrimaryBufferSah = 250.0f;
 bool primary_via_buffer(const rt_ctx* c) {
     const int mode = c->mode();
     if (mode == kBrute || c->strip < 64 || c->counters || c->primary_path == 1 || c->primary_path == 3) return false;
     if (c->primary_path == 2) return true;
+    if (mode == kBvh4q && c->has_wide && c->stack_need + 2 <= 64) return false;      // packet traversal
     return c->stats.sah_cost > kPrimaryBufferSah;
 }
 
@@ -497,9 +500,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
         RT_HIP(c, up(&r.d_materials, hs.mats.data(), hs.mats.size() * 4));
         RT_HIP(c, up(&r.d_sphere_mat, hs.sphere_mat.data(), hs.sphere_mat.size() * 4));
         RT_HIP(c, up(&r.d_lights, hs.lights8.data(), hs.lights8.size() * 4));
-        // (soup-like trees send their primary rays through the ray-buffer kernel: no wide copy in HBM for them)
-        if (!hs.wide.empty() && (c->primary_path == 3 || hs.sah_cost <= kPrimaryBufferSah))
-            RT_HIP(c, up(&r.d_wide, hs.wide.data(), hs.wide.size() * 4));
+        if (!hs.wide.empty()) RT_HIP(c, up(&r.d_wide, hs.wide.data(), hs.wide.size() * 4));
     }
     const double t2 = now_ms();
 
@@ -507,7 +508,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     st = rt_scene_stats{};
     st.n_tris = n_tris; st.n_spheres = n_spheres; st.n_lights = n_lights;
     st.n_nodes = hs.n_nodes; st.n_leaves = hs.n_leaves; st.max_depth = hs.depth;
-    c->stack_need = hs.stack_need; c->layout = hs.layout;
+    c->stack_need = hs.stack_need; c->layout = hs.layout; c->has_wide = !hs.wide.empty();
     {
         float* lo = &c->bin_grid.lox; float* sc = &c->bin_grid.sx;
         for (int a = 0; a < 3; ++a) {

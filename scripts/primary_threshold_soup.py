@@ -15,12 +15,13 @@ def timeit(fn, reps=3):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for nt, half in ((30000, 0.03), (100000, 0.02), (300000, 0.015), (1000000, 0.01), (3000000, 0.007)):
+for nt, half in ((30000, 0.03), (100000, 0.02), (300000, 0.015), (1000000, 0.01), (3000000, 0.007), (10000000, 0.005)):
     tris = scenes.soup(nt, half_extent=half)
     with rt.Renderer((0,)) as r:
+        r.set_option(rt.OPT_PRIMARY, 3)            # (at upload: builds the wide node copy the packet kernel reads)
         st = r.create_data(tris); r.update_camera(cam)
         out = []
-        for path in (1, 2):
+        for path in (1, 2, 3):
             r.set_option(rt.OPT_PRIMARY, path)
             out.append(timeit(lambda: r.primary_shade_stripes_dev(W, H, 0, H, H, 1, thr, rad, nxt, spp=SPP, seed=1, jitter=True, shade_seed=2)))
-        print(f"soup {nt} half {half}: sah {st['sah_cost']:.0f}: tile {out[0]:.2f} ms, ray-buffer {out[1]:.2f} ms", flush=True)
+        print(f"soup {nt} half {half}: sah {st['sah_cost']:.0f}: tile (ray per lane) {out[0]:.2f} ms, ray-buffer {out[1]:.2f} ms, tile (packet) {out[2]:.2f} ms", flush=True)
