@@ -764,26 +764,28 @@ def test_big_soup_takes_the_auto_paths_and_matches_the_reference_loop(big_soup, 
         sub = idx[:: len(idx) // 2048][:2048]
         assert_parity(got[sub], oracle.trace(oracle.Scene(tris), rays[sub]), "1.5 M soup: auto path vs oracle (2 k sample)")
         r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_AUTO)
-        # (c) primary rays: auto = ray generation + ray-buffer kernel with library scratch; 1 = tile kernel
+        # (c) primary rays: auto = packet tile kernel (every BVH4q tree); 2 = ray generation + ray-buffer kernel with library
+        #     scratch (what auto picks for a soup like this one without the packet form); 1 = tile kernel, one ray per lane
         cam = rt.camera_look_at((0.5, 2.2, 0.5), (0.5, 0.5, 0.5), 45.0, 256 / 192)
         r.update_camera(cam)
         w, h, spp = 256, 192, 4
         m = w * h * spp
         out = {}
-        for path in (0, 1):
+        for path in (0, 1, 2):
             r.set_option(rt.OPT_PRIMARY, path)
             ph, pr = dev_buf(torch, m, 16), dev_buf(torch, m, 32)
-            r.trace_primary_dev(w, h, ph, None if path == 0 else pr, spp=spp, seed=3, jitter=True)
+            r.trace_primary_dev(w, h, ph, None if path == 2 else pr, spp=spp, seed=3, jitter=True)
             torch.cuda.synchronize()
             out[path] = to_np(ph, rt.HIT).copy()
-        assert out[0].tobytes() == out[1].tobytes(), "primary rays: ray-buffer path vs tile kernel"
+        assert out[0].tobytes() == out[1].tobytes(), "primary rays: packet tile kernel vs one ray per lane"
+        assert out[2].tobytes() == out[1].tobytes(), "primary rays: ray-buffer path vs tile kernel"
         o_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=3, jitter=True)
         pidx = np.sort(np.random.default_rng(12).choice(m, 1024, replace=False))
         assert_parity(out[0][pidx], oracle.trace(oracle.Scene(tris), o_rays[pidx]), "1.5 M soup: primary sample vs oracle")
 
 
 def test_c5_shaped_path_traced_frame_stage_by_stage():
-    """C5's workload in small: a soup (SAH cost > 250, so segment 0 takes the ray-buffer path on its own) with emitters, a
+    """C5's workload in small: a soup (SAH cost > 250) with emitters, a
     pinhole camera from rt_camera_look_at, 16 spp, 3 bounces, through the fused entry points C5 uses
     (rt_primary_shade_stripes_dev, rt_trace_dev, rt_shade_dev, rt_shade_resolve_dev).  Every stage against orc_shade /
     orc_resolve: bounce rays, throughput, radiance and the linear frame bit-exact, RGBA8 within 1 LSB."""
