@@ -46,6 +46,31 @@ def main():
         print("  by class:", classes(ins))
         print("  by opcode:", ", ".join("%s x%d" % kv for kv in sorted(ops(ins).items(), key=lambda kv: -kv[1])))
         for i in ins: print("    " + i)
+    packet_report(text)
+
+def packet_report(text):
+    """node step of the packet walk (k_primary_packet<no counters, no shading>): the first block that fetches a wide node"""
+    m = re.search(r"^(_ZN2rt12_GLOBAL__N_116k_primary_packetILb0ELb0EEE[^:\n]*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    if not m: return
+    blocks, cur, name = [], [], "entry"
+    for l in m.group(2).split("\n"):
+        s_ = l.strip()
+        if s_.startswith(".LBB") or s_.startswith("; %bb."):
+            if cur: blocks.append((name, cur))
+            cur, name = [], s_.split(":")[0].lstrip("; ")
+            continue
+        if s_ and not s_.startswith(";") and not s_.startswith("."): cur.append(s_.split(";")[0].strip())
+    if cur: blocks.append((name, cur))
+    cand = [b for b in blocks if any(i.startswith("s_load_dwordx16") for i in b[1]) and any(i.startswith("v_pk_fma") for i in b[1])]
+    if not cand: return
+    nm, ins = min(cand, key=lambda b: sum(i.startswith("v_") for i in b[1]))     # an octant-specialised copy (the generic one has 24 more min/max)
+    valu = [i for i in ins if i.startswith("v_")]
+    print("\n== packet walk, node step of one direction octant (k_primary_packet<no counters, no shading>): block %s, %d instructions, %d VALU "
+          "(the scalar child ordering and the pushes follow in the next blocks) ==" % (nm, len(ins), len(valu)))
+    c = collections.Counter(i.split()[0] for i in ins)
+    print("  by opcode:", ", ".join("%s x%d" % kv for kv in sorted(c.items(), key=lambda kv: -kv[1])))
+    for i in ins: print("    " + i)
+
 
 if __name__ == "__main__":
     main()
