@@ -542,6 +542,29 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const rt_ray* __re
     flush_counters<COUNT>(c, live, counters);
 }
 
+// Ray buffers whose consecutive rays are coherent (RT_OPT_RAY_PACKETS): each wave takes 64 consecutive rays and walks the
+// tree as one packet (trace_packet).  Correct for any buffer -- every ray still tests a superset of its own nodes -- but
+// only fast when the 64 rays of a wave really travel together.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_trace_packet(DevScene s, const rt_ray* __restrict__ rays, uint64_t n, const uint32_t* __restrict__ perm,
+                    float4* __restrict__ hits, unsigned long long* counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool in = i < n;
+    const uint64_t my = in ? (perm ? (uint64_t)perm[i] : i) : 0;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = make_float4(0, 0, 0, 0);
+    if (in) { const float4* rp = reinterpret_cast<const float4*>(rays + my); r0 = rp[0]; r1 = rp[1]; }
+    const bool live = in && r1.w > r0.w;
+    const f3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
+    Counters c = { 0, 0, 0, 0 };
+    Best b;
+    b.t = r1.w; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
+    if (live) spheres_pass<COUNT>(s, o, d, r0.w, b, c);
+    trace_packet<COUNT>(s, o, d, r0.w, live, b, c);
+    if (in) hits[my] = pack_hit(b, r1.w);
+    flush_counters<COUNT>(c, live, counters);
+}
+
 // Ray-buffer closest-hit / any-hit with in-wave refill ("strip" kernel).  Incoherent rays finish at very
 // different times (C3 bounce rays: 14 nodes on average, several times that for the slowest lane of a wave), so a
 // lock-step wave idles most lanes.  Here the grid is persistent: a wave draws chunks of `strip` consecutive rays
@@ -1437,6 +1460,17 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
     hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 0);
     hipLaunchKernelGGL(k_bin2_scatter_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, tmp_idx, n, per_block, hist, totals, meta, perm);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_packets(const DevScene& s, bool count, const rt_ray* d_rays, uint64_t n, const uint32_t* d_perm,
+                                rt_hit* d_hits, unsigned long long* d_counters, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (!s.wide || s.stack_depth + 2 > 64) return hipErrorInvalidValue;
+    dim3 g(grid_for(n)), b(kBlock);
+    float4* hits = reinterpret_cast<float4*>(d_hits);
+    if (count) hipLaunchKernelGGL((k_trace_packet<true>), g, b, 0, st, s, d_rays, n, d_perm, hits, d_counters);
+    else       hipLaunchKernelGGL((k_trace_packet<false>), g, b, 0, st, s, d_rays, n, d_perm, hits, d_counters);
     return hipGetLastError();
 }
 

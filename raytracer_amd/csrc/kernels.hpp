@@ -61,6 +61,9 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
 //   lds_cap    stack entries per lane kept in LDS when spill is given
 //   max_blocks bound on the persistent grid (0 = none): the spill area holds one column per thread of the grid
 struct StripScratch { unsigned long long* work = nullptr; int* spill = nullptr; int lds_cap = 0; uint32_t max_blocks = 0; };
+// closest hit for a buffer whose consecutive rays (after d_perm, if given) are coherent: 64 rays per wave walk as one packet
+hipError_t launch_trace_packets(const DevScene& s, bool count, const rt_ray* d_rays, uint64_t n, const uint32_t* d_perm,
+                                rt_hit* d_hits, unsigned long long* d_counters, hipStream_t st);
 hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, const rt_ray* d_rays, uint64_t n,
                         rt_hit* d_hits, uint8_t* d_occ, unsigned long long* d_counters, hipStream_t st,
                         uint32_t strip /* rays per chunk, 0 = one ray per lane */, int refill /* idle lanes that trigger a refill */,

@@ -162,6 +162,7 @@ struct rt_ctx {
     int ray_pad = 1;            // per-ray box pad (kernels.hip make_slab): 1 on, 0 off (measurement only: far origins then lose hits)
     int max_leaf = 4;
     int sah_bins = 16;          // SAH bins per axis of the builder
+    int ray_packets = 0;        // closest-hit ray buffers walk as packets of 64 consecutive rays (RT_OPT_RAY_PACKETS)
     int sah_trav_x100 = 120;    // SAH cost of an interior step, in hundredths of a triangle test
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (12 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold (profiles/r02v_sweep_refill.txt)
@@ -238,6 +239,11 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
                       uint8_t* d_occ, hipStream_t st) {
     if (n == 0) return hipSuccess;
     const int mode = c->mode();
+    if (c->ray_packets && !any_hit && mode == kBvh4q && c->has_wide && c->stack_need + 2 <= 64) {
+        DevScene ds = c->dev_scene(r);
+        ds.wide = reinterpret_cast<const uint32_t*>(r.d_wide);
+        return launch_trace_packets(ds, count, d_rays, n, nullptr, d_hits, r.d_counters, st);
+    }
     const bool strip_kernel = mode != kBrute && c->strip >= 64;
     const bool bin = wants_binning(c, mode, n);
     const uint32_t* perm = nullptr;
@@ -446,6 +452,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) try {
         case RT_OPT_REFILL:      if ((v & 0xff) < 1 || (v & 0xff) > 64 || (v >> 8) > 64) return fail(c, RT_E_INVALID, "RT_OPT_REFILL: low byte 1..64 idle lanes, bits 8.. = leaf-vote threshold 0..64"); c->refill = (int)v; return RT_OK;
         case RT_OPT_SAH_BINS:    if (v < 4 || v > 32) return fail(c, RT_E_INVALID, "RT_OPT_SAH_BINS in [4,32]"); c->sah_bins = (int)v; return RT_OK;
         case RT_OPT_SAH_TRAV:    if (v < 1 || v > 10000) return fail(c, RT_E_INVALID, "RT_OPT_SAH_TRAV in [1,10000] (hundredths)"); c->sah_trav_x100 = (int)v; return RT_OK;
+        case RT_OPT_RAY_PACKETS: if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PACKETS: 0 off, 1 on"); c->ray_packets = (int)v; return RT_OK;
         case RT_OPT_RAY_PAD:     if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PAD: 0 off, 1 on"); c->ray_pad = (int)v; return RT_OK;
         default: return fail(c, RT_E_INVALID, "unknown option key");
     }

@@ -318,6 +318,30 @@ def test_two_level_binning_of_large_buffers(renderer, torch_dev):
     renderer.set_option(rt.OPT_RAY_BINNING, 2)
 
 
+def test_ray_buffer_as_packets_gives_the_same_records(renderer, torch_dev):
+    """RT_OPT_RAY_PACKETS: 64 consecutive rays of a buffer walk the tree as one packet.  Whatever the rays -- here random
+    ones, the worst case for speed, with dead and short rays and a ragged count -- the hit records are the per-ray ones."""
+    n = 20000 + 37
+    st, rays = scenes.soup(20000, half_extent=0.03), scenes.random_rays(n)
+    rays["tmax"][::5] = 0.0
+    rays["tmax"][3::11] = 0.05
+    sph = np.zeros(2, dtype=rt.SPHERE); sph["center"] = [(0.3, 0.3, 0.3), (0.7, 0.6, 0.5)]; sph["radius"] = [0.05, 0.08]
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH4Q)
+    renderer.create_data(st, sph)
+    d_rays = to_dev(torch_dev, rays)
+    out = {}
+    for packets in (0, 1):
+        renderer.set_option(rt.OPT_RAY_PACKETS, packets)
+        hits = dev_buf(torch_dev, n, 16)
+        renderer.trace_dev(d_rays, n, hits)
+        torch_dev.cuda.synchronize()
+        out[packets] = to_np(hits, rt.HIT).copy()
+    assert out[0].tobytes() == out[1].tobytes()
+    idx = np.sort(np.random.default_rng(8).choice(n, 1024, replace=False))
+    assert_parity(out[1][idx], oracle.trace(oracle.Scene(st, sph), rays[idx]), "packets of random rays vs oracle")
+    renderer.set_option(rt.OPT_RAY_PACKETS, 0)
+
+
 def test_capped_lds_stack_with_spill_changes_nothing(renderer, torch_dev):
     """RT_OPT_LDS_STACK: the ray-buffer kernel keeps only the first entries of a lane's stack in LDS and spills deeper ones
     to HBM.  Caps 2 and 3 force nearly every push through the spill path; every cap must give the uncapped records."""
