@@ -48,7 +48,29 @@ static void build_and_flatten(const std::vector<Triangle>& tris, int max_leaf, i
     BuildResult br;
     build_bvh2(boxes.data(), (uint32_t)boxes.size(), bp, br);
     FlatBvh2 f2; flatten_bvh2(br, 1e-5f, f2);
-    FlatBvh4q f4; flatten_bvh4q(br, 1e-5f, f4);
+    FlatBvh4q f4; flatten_bvh4q(br, 1e-5f, f4, /*want_wide=*/true);
+    // the fp32 "wide" copy (packet traversal): same child references as the quantised node; every real child box lies
+    // inside the quantised box of that child (which was rounded outwards from it); empty slots sit at +3e38
+    EXPECT(f4.wide.size() == (size_t)f4.n_nodes * 32);
+    for (uint32_t k = 0; k < f4.n_nodes && f4.wide.size() == (size_t)f4.n_nodes * 32; ++k) {
+        const uint32_t* q = &f4.nodes[(size_t)k * 16];
+        const uint32_t* w = &f4.wide[(size_t)k * 32];
+        const uint32_t n_children = q[3] >> 24;
+        EXPECT(w[4] == n_children);
+        float org[3]; std::memcpy(org, q, 12);
+        for (uint32_t c = 0; c < 4; ++c) {
+            EXPECT(w[c] == q[4 + c]);
+            for (int a = 0; a < 3; ++a) {
+                float lo, hi; std::memcpy(&lo, &w[8 + 6 * c + 2 * a], 4); std::memcpy(&hi, &w[8 + 6 * c + 2 * a + 1], 4);
+                if (c >= n_children) { EXPECT(lo == 3.0e38f && hi == 3.0e38f); continue; }
+                const double sc = std::ldexp(1.0, (int)((q[3] >> (8 * a)) & 0xffu) - 127);
+                const uint32_t lw = q[8 + a], hw = q[a == 0 ? 11 : 12 + (a - 1)];
+                const double qlo = (double)org[a] + sc * (double)((lw >> (8 * c)) & 0xffu), qhi = (double)org[a] + sc * (double)((hw >> (8 * c)) & 0xffu);
+                EXPECT(lo <= hi);
+                EXPECT(qlo <= (double)lo && (double)hi <= qhi);
+            }
+        }
+    }
     EXPECT(f2.tri_order.size() == tris.size());
     EXPECT(f4.tri_order.size() == tris.size());
     EXPECT(f2.nodes.size() == (size_t)f2.n_nodes * 16);
