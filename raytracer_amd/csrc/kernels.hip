@@ -3,9 +3,12 @@
 // What is computed follows shaders/frag.glsl of the reference (paths relative to /root/reference):
 //   getCameraRay :89-128, rayIntersectsTriangle :130-156, rayIntersectsSphere :158-183,
 //   traceRay :265-301, shadow query :321-330, sampleHemisphere :185-203 + offset :340-343.
-// How it is computed is build-original: one ray per lane of a wave64, 8x8-pixel tiles per wave for
-// primary rays, a per-lane traversal stack in LDS ([entry][thread] so every lane owns one bank
-// column), interior nodes as 64-B SoA child pairs, triangles as 48-B (v0,e1,e2) records.
+// How it is computed is build-original.  Incoherent rays (ray buffers: bounce rays, random rays): one ray per lane of a
+// wave64, a per-lane traversal stack in LDS ([entry][thread], every lane owns one bank column) with a spill cap, 64-B
+// nodes with four 8-bit-quantised children (or two fp32 ones), persistent waves that refill idle lanes (k_trace_strip).
+// Coherent rays (the primary rays of a pixel tile, the shadow rays of a tile to one light): the WAVE walks the tree as
+// one packet -- nodes through scalar loads from an fp32 copy, the stack in one VGPR, decisions in scalar code
+// (trace_packet, k_primary_packet).  Triangles are 48-B (v0, e1, e2) records in leaf order.
 //
 // Canonical fp32 evaluation order (must be compiled with -ffp-contract=off; the CPU oracle fixes the
 // same order independently, DESIGN.md "Arithmetic contract"):
@@ -900,7 +903,10 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
     return true;
 }
 
-// Primary rays (frag.glsl:89-128) fused with traceRay.  One wave = one 8x8 pixel tile for one sample.
+// Primary rays (frag.glsl:89-128) fused with traceRay: the "tile kernel".  One wave = a 4x4 pixel tile x 4 samples,
+// 8x4 x 2 or 8x8 x 1 (the largest sample group that divides spp).  Two forms share this body: one ray per lane with its
+// own stack in LDS (k_primary: any layout), and the packet walk of the whole wave (k_primary_packet: BVH4q trees with the
+// wide node copy; the default).
 // With SHADE the first segment of the path loop (:310-354, throughput 1, radiance 0) runs in the same kernel:
 // the primary ray and its hit never travel through HBM (rays_out / hits become optional outputs), and the
 // path-state buffers are written once instead of filled, read and written.
