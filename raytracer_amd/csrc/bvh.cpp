@@ -393,26 +393,31 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out, bool want_wi
                 org[a] = std::min(org[a], lo[k][a]); top[a] = std::max(top[a], hi[k][a]);
             }
         }
-        uint32_t ebyte[3];
+        float scale[3];
         for (int a = 0; a < 3; ++a) {
-            // smallest power of two 2^e with origin + 255 * 2^e >= top (checked in double; all inputs are floats)
-            double ext = (double)top[a] - (double)org[a];
-            int e = -126;
-            if (ext > 0.0) { int ee; std::frexp(ext / 255.0, &ee); e = std::max(ee, -126); }
-            while (std::ldexp(255.0, e) < ext) ++e;
-            if (e > 127) e = 127;
-            ebyte[a] = (uint32_t)(e + 127);
-            const double sc = std::ldexp(1.0, e);
+            // grid step of the axis: the smallest float sc with origin + 255 * sc >= top (checked in double; all inputs are
+            // floats).  Not a power of two: a step of ext/255 instead of up to twice that keeps the quantised boxes tight.
+            const double ext = (double)top[a] - (double)org[a];
+            float sc = 1.0e-30f;
+            if (ext > 0.0) {
+                const double want = std::min(ext / 255.0, 1.0e36);
+                sc = (float)want;
+                if ((double)sc < want) sc = std::nextafterf(sc, 3.0e38f);
+                if (!(sc > 0.f)) sc = 1.0e-30f;
+                while ((double)sc * 255.0 < ext && sc < 1.0e36f) sc = std::nextafterf(sc, 3.0e38f);
+            }
+            scale[a] = sc;
+            const double scd = (double)sc;
             for (int k = 0; k < w.n; ++k) {
-                double ql = std::floor(((double)lo[k][a] - (double)org[a]) / sc);
-                double qh = std::ceil(((double)hi[k][a] - (double)org[a]) / sc);
+                double ql = std::floor(((double)lo[k][a] - (double)org[a]) / scd);
+                double qh = std::ceil(((double)hi[k][a] - (double)org[a]) / scd);
                 if (ql < 0) ql = 0;
                 if (ql > 255) ql = 255;
                 if (qh > 255) qh = 255;
                 if (qh < 0) qh = 0;
-                // guard the conservative property against the fp32 arithmetic the kernel uses
-                while (ql > 0 && (double)org[a] + ql * sc > (double)lo[k][a]) ql -= 1;
-                while (qh < 255 && (double)org[a] + qh * sc < (double)hi[k][a]) qh += 1;
+                // guard the conservative property against the rounding of the divisions above
+                while (ql > 0 && (double)org[a] + ql * scd > (double)lo[k][a]) ql -= 1;
+                while (qh < 255 && (double)org[a] + qh * scd < (double)hi[k][a]) qh += 1;
                 const uint32_t l8 = (uint32_t)ql, h8 = (uint32_t)qh;
                 const int lo_word = 8 + a;                       // q2.x/y/z = lo planes
                 const int hi_word = (a == 0) ? 11 : 12 + (a - 1);  // q2.w = hi.x, q3.x = hi.y, q3.y = hi.z
@@ -431,7 +436,7 @@ void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out, bool want_wi
                 }
         }
         std::memcpy(&q[0], &org[0], 4); std::memcpy(&q[1], &org[1], 4); std::memcpy(&q[2], &org[2], 4);
-        q[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16) | ((uint32_t)w.n << 24);
+        std::memcpy(&q[3], &scale[0], 4); std::memcpy(&q[14], &scale[1], 4); std::memcpy(&q[15], &scale[2], 4);
         for (int k = 0; k < 4; ++k) {
             int32_t r = (k < w.n) ? ref[w.child[k]] : leaf_ref(0, 1);
             std::memcpy(&q[4 + k], &r, 4);

@@ -67,10 +67,11 @@ void flatten_bvh2(const BuildResult& b, float pad, FlatBvh2& out);
 // ---- 4-wide, quantised layout ("BVH4q") ---------------------------------------------------------
 // Incoherent traversal on CDNA4 is bound by the vector-memory path (one pass per cache line per load
 // instruction), not by VALU, so the node packs FOUR children into the 64 B that BVH2 spends on two:
-//   q0 = (origin.x, origin.y, origin.z, bits: ex | ey<<8 | ez<<16 | n_children<<24)   ex.. = biased fp32 exponents
+//   q0 = (origin.x, origin.y, origin.z, scale.x)           fp32 grid step per axis, about extent / 255 (NOT a power of two)
 //   q1 = child references 0..3 (same encoding as BVH2)
-//   q2 = (lo.x[0..3], lo.y[0..3], lo.z[0..3], hi.x[0..3])     one byte per child, plane = origin + 2^e * q
-//   q3 = (hi.y[0..3], hi.z[0..3], 0, 0)                        only the first 8 bytes are fetched
+//   q2 = (lo.x[0..3], lo.y[0..3], lo.z[0..3], hi.x[0..3])     one byte per child, plane = origin + scale * q
+//   q3 = (hi.y[0..3], hi.z[0..3], scale.y, scale.z)
+// Empty slots are stored inverted (lo bytes 255, hi bytes 0).
 // Quantisation rounds lo down and hi up from the PADDED child box, so every quantised box contains the box
 // BVH2 would have used: traversal stays conservative and results stay identical to the brute-force loop.
 struct FlatBvh4q {

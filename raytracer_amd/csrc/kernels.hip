@@ -230,12 +230,14 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
     const int pidx = sp - 1;
     int popped = stk[(CAPPED ? min(pidx, spill.cap - 1) : pidx) * kBlock];
     const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-    const uint32_t w = q0.w;
-    if (COUNT) { ++c.nodes; c.box += w >> 24; }
+    if (COUNT) {                                  // children = slots that are not stored inverted (lo.x 255, hi.x 0)
+        ++c.nodes;
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) c.box += (((q2.x >> (8 * k)) & 0xffu) == 255u && ((q2.w >> (8 * k)) & 0xffu) == 0u) ? 0u : 1u;
+    }
     const float idx = sl.ix, idy = sl.iy, idz = sl.iz;
-    const float sx = __uint_as_float((w << 23) & 0x7f800000u) * idx;
-    const float sy = __uint_as_float((w << 15) & 0x7f800000u) * idy;
-    const float sz = __uint_as_float((w << 7) & 0x7f800000u) * idz;
+    // grid step of the node's axes times 1/d: three multiplies (the steps are plain floats in the node)
+    const float sx = __uint_as_float(q0.w) * idx, sy = __uint_as_float(q3.z) * idy, sz = __uint_as_float(q3.w) * idz;
     const v2f sx2 = (v2f){ sx, sx }, sy2 = (v2f){ sy, sy }, sz2 = (v2f){ sz, sz };
     // (entry, exit) constants of the node: grid origin * idir + the ray's entry constant, the exit side 2 m |idir| later
     const float aex = __fmaf_rn(__uint_as_float(q0.x), idx, sl.ex), aey = __fmaf_rn(__uint_as_float(q0.y), idy, sl.ey),
@@ -295,11 +297,10 @@ __device__ __forceinline__ int bvh4q_step(const float4* __restrict__ nodes, int 
         if (key[1] != miss) { st_write(stk, spill, s, ref[1]); ++s; }
     }
     const bool any = key[0] != miss;             // key[0] is the minimum: a miss there means four misses
-    // All four quarters of the node are fetched as 16-byte loads, and the unused half of the last one is kept "live" up to
-    // here (an empty statement, no instruction): left to itself the register allocator may hand that dead half to the NEXT
-    // load of the group (seen: v[14:17] / v[16:19]), and two loads in flight with overlapping destinations cost trees
-    // that do not fit the caches 12 % (C4: 25.5 -> 28.5 ms, profiles/r02s_c4_regression.txt).
-    asm volatile("" :: "v"(q3.z), "v"(q3.w));
+    // (All four quarters of the node are fetched as 16-byte loads and every word of them is used.  When half of the last
+    // quarter was still unused, the register allocator could hand that dead half to the NEXT load of the group -- seen:
+    // v[14:17] / v[16:19] -- and two loads in flight with overlapping destinations cost trees that do not fit the caches
+    // 12 %: C4 25.5 -> 28.5 ms, profiles/r02s_c4_regression.txt.  scripts/check_load_overlap.py watches for it.)
 #ifdef RT_PROBE_DEADPOP
     if (COUNT && !any && probe_hits_unbounded) ++c.spheres;   // probe build: steps in which all four children miss ONLY because of the current best t
 #endif

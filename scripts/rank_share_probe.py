@@ -32,4 +32,4 @@ for world in (1, 2, 4, 8):
     torch.cuda.synchronize()
     st = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
     print(f"   stages: primary+seg0 {st[0]:.3f}  bounce {st[1]:.3f}  last+resolve {st[2]:.3f} ms", flush=True)
-    print(f"rank 0 of {world}: {ms:.3f} ms/step  (N = 1 step / N = {7.23 / world:.3f})", flush=True)
+    print(f"rank 0 of {world}: {ms:.3f} ms/step  (ideal: the N = 1 step / N)", flush=True)

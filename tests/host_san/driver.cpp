@@ -55,15 +55,17 @@ static void build_and_flatten(const std::vector<Triangle>& tris, int max_leaf, i
     for (uint32_t k = 0; k < f4.n_nodes && f4.wide.size() == (size_t)f4.n_nodes * 32; ++k) {
         const uint32_t* q = &f4.nodes[(size_t)k * 16];
         const uint32_t* w = &f4.wide[(size_t)k * 32];
-        const uint32_t n_children = q[3] >> 24;
+        uint32_t n_children = 0;                                   // slots that are not stored inverted (lo.x 255, hi.x 0)
+        for (uint32_t c = 0; c < 4; ++c) n_children += (((q[8] >> (8 * c)) & 0xffu) == 255u && ((q[11] >> (8 * c)) & 0xffu) == 0u) ? 0u : 1u;
         EXPECT(w[4] == n_children);
         float org[3]; std::memcpy(org, q, 12);
+        float scl[3]; std::memcpy(&scl[0], &q[3], 4); std::memcpy(&scl[1], &q[14], 4); std::memcpy(&scl[2], &q[15], 4);
         for (uint32_t c = 0; c < 4; ++c) {
             EXPECT(w[c] == q[4 + c]);
             for (int a = 0; a < 3; ++a) {
                 float lo, hi; std::memcpy(&lo, &w[8 + 6 * c + 2 * a], 4); std::memcpy(&hi, &w[8 + 6 * c + 2 * a + 1], 4);
                 if (c >= n_children) { EXPECT(lo == 3.0e38f && hi == 3.0e38f); continue; }
-                const double sc = std::ldexp(1.0, (int)((q[3] >> (8 * a)) & 0xffu) - 127);
+                const double sc = (double)scl[a];
                 const uint32_t lw = q[8 + a], hw = q[a == 0 ? 11 : 12 + (a - 1)];
                 const double qlo = (double)org[a] + sc * (double)((lw >> (8 * c)) & 0xffu), qhi = (double)org[a] + sc * (double)((hw >> (8 * c)) & 0xffu);
                 EXPECT(lo <= hi);

@@ -24,12 +24,12 @@ def decode_children(layout, node):
         out.append((np.array([f[4], f[6], f[10]]), np.array([f[5], f[7], f[11]]), int(refs[1])))
         return out
     org = node[0:3].view(np.float32).astype(np.float64)
-    w = int(node[3])
-    scale = np.array([2.0 ** (((w >> (8 * a)) & 0xff) - 127) for a in range(3)])
-    n = w >> 24
+    scale = np.array([node[3:4].view(np.float32)[0], node[14:15].view(np.float32)[0], node[15:16].view(np.float32)[0]], dtype=np.float64)
     refs = node[4:8].view(np.int32)
     lo_words = [int(node[8]), int(node[9]), int(node[10])]
     hi_words = [int(node[11]), int(node[12]), int(node[13])]
+    # empty slots are stored inverted (lo bytes 255, hi bytes 0); real children fill the slots from 0 up
+    n = sum(1 for k in range(4) if not (((lo_words[0] >> (8 * k)) & 0xff) == 255 and ((hi_words[0] >> (8 * k)) & 0xff) == 0))
     for k in range(n):
         ql = np.array([(lo_words[a] >> (8 * k)) & 0xff for a in range(3)], dtype=np.float64)
         qh = np.array([(hi_words[a] >> (8 * k)) & 0xff for a in range(3)], dtype=np.float64)
