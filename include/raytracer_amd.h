@@ -79,8 +79,8 @@ enum {
                                Same rays, hits and path state in every case. */
     RT_OPT_SAH_BINS = 12,   /* BVH builder: SAH bins per axis, 4..32 (default 16); takes effect at upload.  Results are unaffected. */
     RT_OPT_SAH_TRAV = 13,   /* BVH builder: SAH cost of one interior step in hundredths of a triangle test (default 120) */
-    RT_OPT_RAY_PACKETS = 15,/* rt_trace_dev / rt_trace (closest hit, BVH4q trees): 1 = every 64 consecutive rays of the buffer walk the
-                               tree together as one packet, like the primary rays of the tile kernel.  Same hit records for any
+    RT_OPT_RAY_PACKETS = 15,/* rt_trace_dev / rt_trace (closest hit) and rt_shadow_dev, BVH4q trees: 1 = every 64 consecutive rays of
+                               the buffer walk the tree together as one packet, like the primary rays of the tile kernel.  Same hit records for any
                                buffer; faster only when consecutive rays really travel together (same region, similar
                                direction), slower -- possibly much -- when they do not.  Default 0. */
     RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for

@@ -1019,28 +1019,42 @@ void k_primary_packet(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_
 }
 
 // frag.glsl:321-330 for one light, fused: shadow-ray build + closest-hit + lit test.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __restrict__ rays,
-                                                   const float4* __restrict__ hits, uint64_t n, float lx, float ly,
-                                                   float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
-    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
+// PACKET (RT_OPT_RAY_PACKETS, BVH4q trees with the wide node copy): the 64 shadow rays of a wave walk the tree together
+// (trace_packet) -- right when consecutive rays come from neighbouring surface points, as the hits of primary rays in pixel
+// order do; the flags are the same for any buffer.
+template <int MODE, bool PACKET>
+__device__ __forceinline__ void shadow_body(int* stack, const DevScene& s, const rt_ray* __restrict__ rays,
+                                            const float4* __restrict__ hits, uint64_t n, float lx, float ly,
+                                            float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4* rp = reinterpret_cast<const float4*>(rays + i);
-    float4 r0 = rp[0], r1 = rp[1];
-    f3 p, nn;
-    if (!hit_point(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), hits[i], p, nn)) {
-        lit[i] = 2;
-        if (srays) { srays[2 * i] = make_float4(0, 0, 0, 0); srays[2 * i + 1] = make_float4(0, 0, 0, 0); }
-        return;
+    const bool in = i < n;
+    if (!PACKET && !in) return;
+    f3 p = mk(0.0f, 0.0f, 0.0f), nn = mk(0.0f, 0.0f, 1.0f);
+    bool valid = false;
+    if (in) {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        float4 r0 = rp[0], r1 = rp[1];
+        valid = hit_point(s, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), hits[i], p, nn);
+        if (!valid) {
+            lit[i] = 2;
+            if (srays) { srays[2 * i] = make_float4(0, 0, 0, 0); srays[2 * i + 1] = make_float4(0, 0, 0, 0); }
+        }
     }
+    if (!PACKET && !valid) return;
     f3 toL = sub3(mk(lx, ly, lz), p);
     f3 L = norm3(toL);                                       // :321
     float distance = sqrtf(dot3(toL, toL));                  // :322
     f3 so = madd3(0.001f, nn, p);                            // :326
     Best b; Counters c = { 0, 0, 0, 0 };
     const float tmax = 1e20f;
-    trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
+    if (PACKET) {
+        b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
+        if (valid) spheres_pass<false>(s, so, L, 0.0f, b, c);
+        trace_packet<false>(s, so, L, 0.0f, valid, b, c);
+        if (!valid) return;
+    } else {
+        trace_ray<MODE, false, false>(s, so, L, 0.0f, tmax, b, c, stack + (MODE != kBrute ? threadIdx.x : 0));
+    }
     bool is_lit = true;
     if (b.t < tmax) {
         f3 dl = sub3(madd3(b.t, L, so), p);
@@ -1048,6 +1062,18 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __r
     }
     lit[i] = is_lit ? 1 : 0;
     if (srays) { srays[2 * i] = make_float4(so.x, so.y, so.z, 0.0f); srays[2 * i + 1] = make_float4(L.x, L.y, L.z, tmax); }
+}
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene s, const rt_ray* __restrict__ rays,
+                                                   const float4* __restrict__ hits, uint64_t n, float lx, float ly,
+                                                   float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
+    extern __shared__ int stack[];      // (depth + 2) entries x kBlock threads, sized at launch
+    shadow_body<MODE, false>(stack, s, rays, hits, n, lx, ly, lz, srays, lit);
+}
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_shadow_packet(DevScene s, const rt_ray* __restrict__ rays, const float4* __restrict__ hits, uint64_t n, float lx, float ly,
+                     float lz, float4* __restrict__ srays, uint8_t* __restrict__ lit) {
+    shadow_body<kBvh4q, true>(nullptr, s, rays, hits, n, lx, ly, lz, srays, lit);
 }
 
 // frag.glsl:185-203 (cos(theta) = sqrt(1-xi1), sin(theta) = sqrt(xi1) folded analytically) + :340-343.
@@ -1633,12 +1659,15 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
 }
 
 hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, float lx,
-                         float ly, float lz, rt_ray* d_shadow_rays, uint8_t* d_lit, hipStream_t st) {
+                         float ly, float lz, rt_ray* d_shadow_rays, uint8_t* d_lit, hipStream_t st, bool packets) {
     if (n == 0) return hipSuccess;
     dim3 g(grid_for(n)), b(kBlock);
     const float4* hits = reinterpret_cast<const float4*>(d_hits);
     float4* sr = reinterpret_cast<float4*>(d_shadow_rays);
 #define RT_LAUNCH_M(M) hipLaunchKernelGGL((k_shadow<M>), g, b, stack_bytes(s, M), st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit)
+    if (packets && mode == kBvh4q && s.wide && s.stack_depth + 2 <= 64)
+        hipLaunchKernelGGL(k_shadow_packet, g, b, 0, st, s, d_rays, hits, n, lx, ly, lz, sr, d_lit);
+    else
     if (mode == kBrute) RT_LAUNCH_M(kBrute); else if (mode == kBvh4q) RT_LAUNCH_M(kBvh4q); else RT_LAUNCH_M(kBvh2);
 #undef RT_LAUNCH_M
     return hipGetLastError();

@@ -99,7 +99,8 @@ hipError_t launch_primary(const DevScene& s, const DevCamera& cam, int mode, boo
                           unsigned long long* d_counters, hipStream_t st, const PrimaryShade* shade = nullptr);
 
 hipError_t launch_shadow(const DevScene& s, int mode, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n,
-                         float lx, float ly, float lz, rt_ray* d_shadow_rays, uint8_t* d_lit, hipStream_t st);
+                         float lx, float ly, float lz, rt_ray* d_shadow_rays, uint8_t* d_lit, hipStream_t st,
+                         bool packets = false /* 64 consecutive shadow rays walk as one packet (needs s.wide) */);
 
 hipError_t launch_bounce(const DevScene& s, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t key0,
                          uint32_t seed, rt_ray* d_out, hipStream_t st);

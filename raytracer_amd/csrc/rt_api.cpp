@@ -684,7 +684,9 @@ int rt_shadow_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit* d_hit
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = HIP's default (null) stream
-    RT_HIP(c, launch_shadow(c->dev_scene(r), c->mode(), d_rays, d_hits, n, lp[0], lp[1], lp[2], d_srays, d_lit, st));
+    DevScene ds = c->dev_scene(r);
+    if (c->ray_packets) ds.wide = reinterpret_cast<const uint32_t*>(r.d_wide);
+    RT_HIP(c, launch_shadow(ds, c->mode(), d_rays, d_hits, n, lp[0], lp[1], lp[2], d_srays, d_lit, st, c->ray_packets != 0));
     return RT_OK;
 } RT_ABI_CATCH(c)
 

@@ -83,6 +83,16 @@ def c2():
             lp = tuple(float(x) for x in lights[0]["position"])
             ms_p = timeit(lambda: r.trace_primary_dev(w, h, hits, rays))
             ms_s = timeit(lambda: r.shadow_dev(rays, hits, n, lp, lit))
+            ms_sp = None
+            if mode == rt.TRAVERSAL_BVH4Q:
+                # the shadow rays start at the hits of primary rays in pixel order: coherent, so they may walk as packets
+                # (RT_OPT_RAY_PACKETS); the flags must not change
+                lit_p = torch.empty(n, dtype=torch.uint8, device=dev)
+                r.set_option(rt.OPT_RAY_PACKETS, 1)
+                ms_sp = timeit(lambda: r.shadow_dev(rays, hits, n, lp, lit_p))
+                r.set_option(rt.OPT_RAY_PACKETS, 0)
+                torch.cuda.synchronize()
+                assert torch.equal(lit, lit_p), "shadow flags differ between per-lane and packet walks"
             hh = hits.cpu().numpy().view(rt.HIT)
             n_shadow = int((hh["prim"] != rt.MISS).sum())
             par = sample_parity(tris, sph, rays.cpu().numpy().view(rt.RAY), hh, 16384)
@@ -90,6 +100,7 @@ def c2():
             o_lit = oracle.shadow_lit(oracle.Scene(tris, sph), rays.cpu().numpy().view(rt.RAY)[idx], hh[idx], lp)
             par["shadow_flag_mismatches"] = int((o_lit != lit.cpu().numpy()[idx]).sum())
             res[name] = {"primary_ms": round(ms_p, 4), "shadow_ms": round(ms_s, 4), "shadow_rays": n_shadow,
+                         **({"shadow_packets_ms": round(ms_sp, 4), "Mrays_s_with_shadow_packets": round((n + n_shadow) / (ms_p + ms_sp) / 1e3, 1)} if ms_sp else {}),
                          "Mrays_s": round((n + n_shadow) / (ms_p + ms_s) / 1e3, 1),
                          "primary_Mrays_s": round(n / ms_p / 1e3, 1), "shadow_Mrays_s": round(n_shadow / ms_s / 1e3, 1),
                          "work_primary": counters_of(r, lambda: r.trace_primary_dev(w, h, hits, rays)),

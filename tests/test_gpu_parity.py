@@ -342,6 +342,35 @@ def test_ray_buffer_as_packets_gives_the_same_records(renderer, torch_dev):
     renderer.set_option(rt.OPT_RAY_PACKETS, 0)
 
 
+def test_shadow_rays_as_packets_give_the_same_flags(renderer, torch_dev):
+    """rt_shadow_dev under RT_OPT_RAY_PACKETS: lit flags and shadow rays of the packet walk equal the per-lane ones, for the
+    coherent case it is meant for (hits of primary rays in pixel order, ragged frame) and for shuffled hits."""
+    tris, sph, lights, cam = scenes.bunny_class()
+    w, h = 123, 77
+    n = w * h
+    renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH4Q)
+    renderer.create_data(tris, sph, lights); renderer.update_camera(cam)
+    rays, hits = dev_buf(torch_dev, n, 32), dev_buf(torch_dev, n, 16)
+    renderer.trace_primary_dev(w, h, hits, rays)
+    torch_dev.cuda.synchronize()
+    lp = tuple(float(x) for x in lights[0]["position"])
+    perm = torch_dev.randperm(n, device="cuda")
+    for label, rr, hh in (("pixel order", rays, hits),
+                          ("shuffled", rays.view(-1, 8)[perm].contiguous().view(-1), hits.view(-1, 4)[perm].contiguous().view(-1))):
+        out = {}
+        for packets in (0, 1):
+            renderer.set_option(rt.OPT_RAY_PACKETS, packets)
+            lit = torch_dev.zeros(n, dtype=torch_dev.uint8, device="cuda")
+            sr = dev_buf(torch_dev, n, 32)
+            renderer.shadow_dev(rr, hh, n, lp, lit, sr)
+            torch_dev.cuda.synchronize()
+            out[packets] = (lit.cpu().numpy().copy(), sr.cpu().numpy().copy())
+        assert np.array_equal(out[0][0], out[1][0]), label
+        assert out[0][1].tobytes() == out[1][1].tobytes(), label
+        assert (out[1][0] == 1).any() and (out[1][0] == 0).any() and (out[1][0] == 2).any()
+    renderer.set_option(rt.OPT_RAY_PACKETS, 0)
+
+
 def test_capped_lds_stack_with_spill_changes_nothing(renderer, torch_dev):
     """RT_OPT_LDS_STACK: the ray-buffer kernel keeps only the first entries of a lane's stack in LDS and spills deeper ones
     to HBM.  Caps 2 and 3 force nearly every push through the spill path; every cap must give the uncapped records."""
