@@ -230,6 +230,78 @@ def test_intervals_degenerates_and_axis_aligned_rays(renderer):
         assert np.array_equal(renderer.occluded(rays), oracle.occluded(sc, rays))
 
 
+def special_value_rays(n, seed):
+    """Random rays in which a third of the records carry IEEE special values (signed zeros, NaN, infinities, denormals,
+    the largest and smallest normals) in random fields: nothing at the boundary validates ray buffers, so every path
+    has to give the reference loop's answer (mostly: no hit) for them, and must not hang."""
+    rng = np.random.default_rng(seed)
+    rays = scenes.random_rays(n, seed=seed)
+    pool = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38,
+                     1e-20, -1e-20, 1e20, 1.0, -1.0], dtype=np.float32)
+    flat = rays.view(np.float32).reshape(n, 8)                     # o.xyz tmin d.xyz tmax
+    for _ in range(2):
+        rows = rng.choice(n, n // 5, replace=False)
+        flat[rows, rng.integers(0, 8, rows.size)] = pool[rng.integers(0, pool.size, rows.size)]
+    rows = rng.choice(n, n // 50, replace=False)                   # axis-parallel with signed zeros, from inside
+    flat[rows, 4:7] = 0.0
+    flat[rows, 4 + rng.integers(0, 3, rows.size)] = rng.choice(np.float32([1, -1]), rows.size)
+    flat[rows[::2], 4 + rng.integers(0, 3, rows[::2].size)] *= np.float32(-1.0)   # 0 -> -0 (or flips the axis)
+    return rays
+
+
+def test_special_value_rays_in_every_path(renderer, torch_dev):
+    n = 24000 + 13
+    st, rays = scenes.soup(6000, half_extent=0.04), special_value_rays(n, 0xBAD5EED)
+    sph = np.zeros(2, dtype=rt.SPHERE); sph["center"] = [(0.3, 0.3, 0.3), (0.7, 0.6, 0.5)]; sph["radius"] = [0.05, 0.08]
+    sc = oracle.Scene(st, sph)
+    ref, ref_occ = oracle.trace(sc, rays), oracle.occluded(sc, rays)
+    hit = ref["prim"] != rt.MISS
+    assert hit.sum() > n // 4 and (~hit).sum() > n // 4
+    d_rays = to_dev(torch_dev, rays)
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q):
+        renderer.set_option(rt.OPT_TRAVERSAL, mode)
+        renderer.create_data(st, sph)
+        for binning, packets in ((0, 0), (1, 0), (0, 1)):
+            renderer.set_option(rt.OPT_RAY_BINNING, binning)
+            renderer.set_option(rt.OPT_RAY_PACKETS, packets)
+            hits, occ = dev_buf(torch_dev, n, 16), torch_dev.zeros(n, dtype=torch_dev.uint8, device="cuda")
+            renderer.trace_dev(d_rays, n, hits)
+            renderer.occluded_dev(d_rays, n, occ)
+            torch_dev.cuda.synchronize()
+            what = f"special-value rays mode {mode} binning {binning} packets {packets}"
+            assert_parity(to_np(hits, rt.HIT), ref, what)
+            assert np.array_equal(occ.cpu().numpy(), ref_occ), what
+    renderer.set_option(rt.OPT_RAY_BINNING, 2)
+    renderer.set_option(rt.OPT_RAY_PACKETS, 0)
+
+
+@pytest.mark.parametrize("scale,offset", [(1e3, 0.0), (1e6, 3e6), (1e12, -7e12), (2.0 ** -4, 40.0)])
+def test_scaled_and_shifted_scenes_keep_parity(renderer, scale, offset):
+    """The same soup in other units and away from the world origin: node grids, per-ray pads and the binning grid all
+    derive from the scene bounds, so nothing may depend on coordinates being of order one.  (Below ~1e-2 the reference's
+    absolute 1e-6 determinant threshold rejects every triangle, above ~1e15 its products overflow: both ends give empty
+    images in the reference too and are not interesting.)"""
+    n = 30000
+    st, rays = scenes.soup(8000, half_extent=0.04), scenes.random_rays(n)
+    rays["o"][: n // 4] = rays["o"][: n // 4] * 6 - 2.5
+    s, off = np.float32(scale), np.float32(offset)
+    for v in ("v0", "v1", "v2"):
+        st[v]["position"] = st[v]["position"] * s + off
+    rays["o"] = rays["o"] * s + off
+    rays["tmax"] = 1e20 if scale < 1e6 else 3e38
+    ref = oracle.trace(oracle.Scene(st), rays)
+    assert (ref["prim"] != rt.MISS).mean() > 0.1
+    for mode in (rt.TRAVERSAL_BRUTE, rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q):
+        renderer.set_option(rt.OPT_TRAVERSAL, mode)
+        renderer.create_data(st)
+        for binning, packets in ((0, 0), (1, 0), (0, 1)):
+            renderer.set_option(rt.OPT_RAY_BINNING, binning)
+            renderer.set_option(rt.OPT_RAY_PACKETS, packets)
+            assert_parity(renderer.trace(rays), ref, f"scale {scale} offset {offset} mode {mode} binning {binning} packets {packets}")
+    renderer.set_option(rt.OPT_RAY_BINNING, 2)
+    renderer.set_option(rt.OPT_RAY_PACKETS, 0)
+
+
 def test_error_conventions(renderer):
     with pytest.raises(RuntimeError, match="no scene"):
         renderer.trace(mk_rays((0, 0, 0), (0, 0, 1)))
