@@ -409,13 +409,20 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
     const float tmin0 = fmaxf(tmin, 0.0f);
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
     const uint32_t miss = 0xffffffffu;
-    int stack = 0;                      // lane i holds stack entry i
-    int sp = 0, node = 0;               // wave-uniform
-    for (;;) {
+    int stack = kDone;                  // lane i holds stack entry i; entry 0 is the sentinel that ends the walk
+    int sp = 1, node = 0;               // wave-uniform
+    const int rep = (int)__builtin_ctzll(act | (1ull << 63));     // the lane whose entry distances order the children
+    // One loop, one exit, every branch wave-uniform: with `continue` / `break` / an empty-stack test in the body the compiler
+    // turned the uniform branches into mask arithmetic (a dozen scalar instructions per node); popping the sentinel ends it
+    // (1.70 -> 1.63 ms; testing `node >= 0` first with a `break` for the sentinel, and selects instead of branches in the
+    // triangle loop, were both slower: profiles/r03q_packet_salu.txt).
+    while (node != kDone) {
         if (node >= 0) {
             // the whole 128-byte node in one go (uniform address: scalar loads), then straight-line code: no child is
             // skipped by a branch -- empty slots carry planes at +3e38 and miss by arithmetic
-            const uint4* np = wide + (size_t)(uint32_t)node * 8;
+            // 32-bit byte offset (the scalar loads take it as their SGPR offset: one shift instead of 64-bit address arithmetic);
+            // rt_api.cpp keeps the wide copy only for trees below 2^25 nodes
+            const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wide) + ((uint32_t)node << 7));
             const uint4 w0 = np[0], w1 = np[1], p0 = np[2], p1 = np[3], p2 = np[4], p3 = np[5], p4 = np[6], p5 = np[7];
             if (COUNT && active) { ++c.nodes; c.box += w1.x; }
             const uint32_t pl[24] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w,
@@ -435,10 +442,15 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
                     tn = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), tmin0);
                     tf = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), b.t);
                 }
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(tn <= tf) & act;
-                // entry distance of the first lane that meets the child (tn >= 0: its bits order like the value)
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(tn), (int)__builtin_ctzll(m | (1ull << 63)));
-                key[k] = m ? first : miss;
+                // The children are ordered by the entry distances of ONE lane of the packet (the first with a ray), whether that
+                // lane meets the child or not; "some lane meets it" and the key select are two scalar instructions (s_and_b64
+                // leaves "result != 0" in SCC).  The scalar unit is what this loop runs out of first -- one more scalar
+                // instruction per node costs as much as four VALU cycles (profiles/r03q_packet_salu.txt) -- and finding the first
+                // lane that meets each child (s_ff1 + a second readlane index + compare) took 15 of them: 1.82 -> 1.71 ms.
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(tn <= tf);
+                const uint32_t tn_rep = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(tn), rep);   // tn >= 0: bits order like the value
+                unsigned long long m;
+                asm("s_and_b64 %0, %2, %3\n\ts_cselect_b32 %1, %4, -1" : "=&s"(m), "=s"(key[k]) : "s"(hm), "s"(act), "s"(tn_rep) : "scc");
             }
             cswap_s(key[0], ref[0], key[1], ref[1]);
             cswap_s(key[2], ref[2], key[3], ref[3]);
@@ -448,7 +460,8 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
             if (key[3] != miss) { stack = write_lane(stack, ref[3], sp); ++sp; }
             if (key[2] != miss) { stack = write_lane(stack, ref[2], sp); ++sp; }
             if (key[1] != miss) { stack = write_lane(stack, ref[1], sp); ++sp; }
-            if (key[0] != miss) { node = ref[0]; continue; }
+            if (key[0] != miss) node = ref[0];
+            else { --sp; node = __builtin_amdgcn_readlane(stack, sp); }
         } else {
             const uint32_t r = ~(uint32_t)node;                               // (first << 3) | (count - 1)
             const uint32_t first = r >> 3, cnt = (r & 7u) + 1u;
@@ -460,10 +473,9 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
                     consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
                 if (COUNT && active) ++c.tris;
             }
+            --sp;
+            node = __builtin_amdgcn_readlane(stack, sp);
         }
-        if (sp == 0) break;
-        --sp;
-        node = __builtin_amdgcn_readlane(stack, sp);
     }
 }
 

@@ -485,6 +485,7 @@ int rt_scene_upload(rt_ctx* c, const void* tris, uint32_t n_tris, uint32_t tri_s
     }
     if (hs.layout == kBvh4q && hs.n_nodes >= (1u << 26))      // the BVH4q step addresses nodes by a 32-bit byte offset
         return fail(c, RT_E_TOO_LARGE, "more than 2^26-1 BVH4q nodes (about 200 M triangles); use RT_OPT_TRAVERSAL 2");
+    if (hs.n_nodes >= (1u << 25)) { std::vector<uint32_t>().swap(hs.wide); }   // the packet walk addresses the 128-byte copy by a 32-bit byte offset: larger trees go without it
     const double t1 = now_ms();
 
     // replicate
