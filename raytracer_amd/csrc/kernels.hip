@@ -386,7 +386,12 @@ __device__ __forceinline__ int write_lane(int vec, int value, int lane) {
     return vec;
 }
 __device__ __forceinline__ void cswap_s(uint32_t& ka, int& ra, uint32_t& kb, int& rb) {
-    if (kb < ka) { const uint32_t k = ka; ka = kb; kb = k; const int r = ra; ra = rb; rb = r; }
+    // s_max_u32 leaves "first operand selected" (ka > kb: swap) in SCC for the two reference selects: 4 scalar instructions
+    // where compare + four selects are 5
+    uint32_t klo, khi; int rlo, rhi;
+    asm("s_min_u32 %0, %4, %5\n\ts_max_u32 %1, %4, %5\n\ts_cselect_b32 %2, %7, %6\n\ts_cselect_b32 %3, %6, %7"
+        : "=&s"(klo), "=&s"(khi), "=&s"(rlo), "=s"(rhi) : "s"(ka), "s"(kb), "s"(ra), "s"(rb) : "scc");
+    ka = klo; kb = khi; ra = rlo; rb = rhi;
 }
 // v_min / v_max as opaque instructions: like fminf / fmaxf they return the non-NaN operand, but the compiler does not
 // put a canonicalising v_max(x, x) in front of every operand it cannot prove quiet (six per child in this loop)
@@ -414,10 +419,10 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
     const int rep = (int)__builtin_ctzll(act | (1ull << 63));     // the lane whose entry distances order the children
     // One loop, one exit, every branch wave-uniform: with `continue` / `break` / an empty-stack test in the body the compiler
     // turned the uniform branches into mask arithmetic (a dozen scalar instructions per node); popping the sentinel ends it
-    // (1.70 -> 1.63 ms; testing `node >= 0` first with a `break` for the sentinel, and selects instead of branches in the
-    // triangle loop, were both slower: profiles/r03q_packet_salu.txt).
-    while (node != kDone) {
-        if (node >= 0) {
+    // (1.70 -> 1.62 ms; an `if` with a `break` for the sentinel in its else branch instead of the inner loop, and selects
+    // instead of branches in the triangle loop, were both slower: profiles/r03q_packet_salu.txt).
+    for (;;) {
+        while (node >= 0) {
             // the whole 128-byte node in one go (uniform address: scalar loads), then straight-line code: no child is
             // skipped by a branch -- empty slots carry planes at +3e38 and miss by arithmetic
             // 32-bit byte offset (the scalar loads take it as their SGPR offset: one shift instead of 64-bit address arithmetic);
@@ -462,7 +467,9 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
             if (key[1] != miss) { stack = write_lane(stack, ref[1], sp); ++sp; }
             if (key[0] != miss) node = ref[0];
             else { --sp; node = __builtin_amdgcn_readlane(stack, sp); }
-        } else {
+        }
+        if (node == kDone) break;
+        {
             const uint32_t r = ~(uint32_t)node;                               // (first << 3) | (count - 1)
             const uint32_t first = r >> 3, cnt = (r & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; ++k) {
@@ -701,6 +708,9 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         // step and ONE triangle test, so no lane waits for the slowest lane's whole descent.  A lane that
         // reaches a leaf parks it in `pend` and keeps walking from its stack; the triangle block is skipped
         // (wave-uniform branch) until at least `tth` lanes hold a parked leaf or no lane can walk any further.
+#ifdef RT_X_DUMMY_S
+        { int dummy; asm volatile("s_mov_b32 %0, 0\n\ts_mov_b32 %0, 1\n\ts_mov_b32 %0, 2\n\ts_mov_b32 %0, 3\n\ts_mov_b32 %0, 4\n\ts_mov_b32 %0, 5\n\ts_mov_b32 %0, 6\n\ts_mov_b32 %0, 7\n\ts_mov_b32 %0, 8\n\ts_mov_b32 %0, 9" : "=s"(dummy)); }
+#endif
         const bool need_i = node >= 0;
         if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); w_idle += __popcll(__ballot(node == kDone && pend == 0)); }
         if (need_i) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
@@ -1021,8 +1031,11 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene s, DevCamera cam, u
 // per SIMD: the traversal loops need 40 VGPRs, the fused shading segment 108.  Asked for 8 waves (64 VGPRs) the allocator
 // spills 33 registers, all of them in the shading code that runs once per ray, none in the traversal loops: primary +
 // segment 0 2.12 -> 1.81 ms (5 waves 1.98, 6 waves 1.92; profiles/r02z_packet.txt).
+#ifndef RT_PACKET_WAVES
+#define RT_PACKET_WAVES 8
+#endif
 template <bool COUNT, bool SHADE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_PACKET_WAVES, 8)))
 void k_primary_packet(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0,
                       uint32_t rows, uint32_t stripe_h, uint32_t stripe_step,
                       uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
