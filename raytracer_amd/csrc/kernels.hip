@@ -708,9 +708,6 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         // step and ONE triangle test, so no lane waits for the slowest lane's whole descent.  A lane that
         // reaches a leaf parks it in `pend` and keeps walking from its stack; the triangle block is skipped
         // (wave-uniform branch) until at least `tth` lanes hold a parked leaf or no lane can walk any further.
-#ifdef RT_X_DUMMY_S
-        { int dummy; asm volatile("s_mov_b32 %0, 0\n\ts_mov_b32 %0, 1\n\ts_mov_b32 %0, 2\n\ts_mov_b32 %0, 3\n\ts_mov_b32 %0, 4\n\ts_mov_b32 %0, 5\n\ts_mov_b32 %0, 6\n\ts_mov_b32 %0, 7\n\ts_mov_b32 %0, 8\n\ts_mov_b32 %0, 9" : "=s"(dummy)); }
-#endif
         const bool need_i = node >= 0;
         if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); w_idle += __popcll(__ballot(node == kDone && pend == 0)); }
         if (need_i) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
