@@ -416,7 +416,11 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
     const uint32_t miss = 0xffffffffu;
     int stack = kDone;                  // lane i holds stack entry i; entry 0 is the sentinel that ends the walk
     int sp = 1, node = 0;               // wave-uniform
-    const int rep = (int)__builtin_ctzll(act | (1ull << 63));     // the lane whose entry distances order the children
+    // the lane whose entry distances order the children: one in the middle of the tile (4x4 pixels x 4 samples, 8x8 pixels or 64
+    // rays in a row: lane 27), the first lane with a ray if that one has none.  A corner lane (lane 0) orders as well on average
+    // but worse for some tiles, and a small launch lasts as long as its slowest wave (1920x1080 primary rays: 0.18 ms with
+    // lane 0, 0.10 ms with lane 27, 0.11 ms ordering by the first lane that meets each child: profiles/r03q_packet_salu.txt)
+    const int rep = ((act >> 27) & 1ull) ? 27 : (int)__builtin_ctzll(act | (1ull << 63));
     // One loop, one exit, every branch wave-uniform: with `continue` / `break` / an empty-stack test in the body the compiler
     // turned the uniform branches into mask arithmetic (a dozen scalar instructions per node); popping the sentinel ends it
     // (1.70 -> 1.62 ms; an `if` with a `break` for the sentinel in its else branch instead of the inner loop, and selects
@@ -447,7 +451,7 @@ __device__ __forceinline__ void packet_walk(const DevScene& s, f3 o, f3 d, float
                     tn = vmax(vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y)), tmin0);
                     tf = vmin(vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y)), b.t);
                 }
-                // The children are ordered by the entry distances of ONE lane of the packet (the first with a ray), whether that
+                // The children are ordered by the entry distances of ONE lane of the packet (`rep`), whether that
                 // lane meets the child or not; "some lane meets it" and the key select are two scalar instructions (s_and_b64
                 // leaves "result != 0" in SCC).  The scalar unit is what this loop runs out of first -- one more scalar
                 // instruction per node costs as much as four VALU cycles (profiles/r03q_packet_salu.txt) -- and finding the first
