@@ -71,7 +71,8 @@ enum {
                                with traversal and, in rt_primary_shade_stripes_dev, with the first shading segment);
                                3 = the same kernel with PACKET traversal: the 64 rays of a wave (a 4x4 .. 8x8 pixel tile)
                                walk the tree together, node by node, from an fp32 copy of the BVH4q nodes fetched with
-                               scalar loads (128 B per node more in HBM; set before rt_scene_upload);
+                               scalar loads (128 B per node more in HBM; set before rt_scene_upload; trees of 2^25 nodes
+                               and more -- over 100 M triangles -- go without the copy and take 1 or 2 by the rule below);
                                2 = ray generation into a buffer + the ray-buffer kernel (+ the first-segment shade);
                                0 auto (default) = 3 for BVH4q trees (ahead on every scene measured, tessellated or soup);
                                for BVH2 trees 2 when the tree's SAH cost (rt_scene_stats.sah_cost) exceeds 250, i.e. for
