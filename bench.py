@@ -337,7 +337,7 @@ def main():
                               "bvh_walk_bit_exact": bool(w_hits.tobytes() == g_hits.tobytes() and w_bhits.tobytes() == g_bhits.tobytes())})
     # ---- SURVEY 8(d) second figure: closest hit INCLUDING the transfers (host rays in, host hits out) ----------------
     # What the reference's frame loop would call with host arrays (rt_trace): 2 Mi-ray pieces, H2D | kernel | D2H
-    # overlapped on two streams.  Never `value`.  The PCIe bound is 32 B in + 16 B out per ray over the measured link rates.
+    # overlapped on four streams (one per copy direction, two for the kernels).  Never `value`.  The PCIe bound is 32 B in + 16 B out per ray over the measured link rates.
     if world == 1 and not quick:
         m = min(n_local, XFER_SAMPLE)
         h_rays = brays.view(-1, 8)[:m].cpu().numpy().view(rt.RAY).ravel()

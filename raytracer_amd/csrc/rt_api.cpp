@@ -92,12 +92,13 @@ private:
 };
 
 // Staging of the host-pointer entry points (rt_trace / rt_occluded): pinned host buffers and device buffers for
-// kPipeRing pieces, two streams, one event per ring slot.
+// kPipeRing pieces, four streams (inbound copies, outbound copies, kernels of even / odd pieces), three events per ring slot.
 struct HostPipe {
     void* pin_in[kPipeRing] = {};  void* pin_out[kPipeRing] = {};
     void* d_in[kPipeRing] = {};    void* d_out[kPipeRing] = {};
     hipEvent_t done[kPipeRing] = {};
-    hipStream_t st[2] = {};
+    hipEvent_t got[kPipeRing] = {}, ran[kPipeRing] = {};     // piece is on the device / its kernels have run
+    hipStream_t st[4] = {};                                  // inbound copies, outbound copies, kernels of even / odd pieces
     uint64_t cap_rays = 0;
     bool ready = false;
     std::unique_ptr<CopyPool> pool;            // staging copies (created on first use)
@@ -372,9 +373,11 @@ void free_pipe(Replica& r) {
         if (p.d_in[k]) (void)hipFree(p.d_in[k]);
         if (p.d_out[k]) (void)hipFree(p.d_out[k]);
         if (p.done[k]) (void)hipEventDestroy(p.done[k]);
-        p.pin_in[k] = p.pin_out[k] = p.d_in[k] = p.d_out[k] = nullptr; p.done[k] = nullptr;
+        if (p.got[k]) (void)hipEventDestroy(p.got[k]);
+        if (p.ran[k]) (void)hipEventDestroy(p.ran[k]);
+        p.pin_in[k] = p.pin_out[k] = p.d_in[k] = p.d_out[k] = nullptr; p.done[k] = p.got[k] = p.ran[k] = nullptr;
     }
-    for (int k = 0; k < 2; ++k) { if (p.st[k]) (void)hipStreamDestroy(p.st[k]); p.st[k] = nullptr; }
+    for (int k = 0; k < 4; ++k) { if (p.st[k]) (void)hipStreamDestroy(p.st[k]); p.st[k] = nullptr; }
     p.cap_rays = 0; p.ready = false;
 }
 
@@ -896,8 +899,12 @@ static bool is_pinned(const void* p) {
 static int pipe_prepare(Replica& r, uint64_t piece, bool stage_in, bool stage_out, size_t osz) {
     HostPipe& p = r.pipe;
     if (!p.ready) {
-        for (int k = 0; k < 2; ++k) RT_HIP_SLOT(r, hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking));
-        for (int k = 0; k < kPipeRing; ++k) RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.done[k], hipEventDisableTiming));
+        for (int k = 0; k < 4; ++k) RT_HIP_SLOT(r, hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking));
+        for (int k = 0; k < kPipeRing; ++k) {
+            RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.done[k], hipEventDisableTiming));
+            RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.got[k], hipEventDisableTiming));
+            RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.ran[k], hipEventDisableTiming));
+        }
         p.ready = true;
     }
     if (piece > p.cap_rays) {                       // device buffers sized for hits (16 B) so that any-hit fits too
@@ -928,7 +935,7 @@ static int pipe_prepare(Replica& r, uint64_t piece, bool stage_in, bool stage_ou
 }
 
 // Host-pointer closest hit / any-hit (what VkRenderer::drawFrame would call, src/vulkan/VkRenderer.cpp:1287-1374): the
-// rays go through the GPU in pieces of kPieceRays, kPipeRing pieces in flight on two streams, so that the staging copy
+// rays go through the GPU in pieces of kPieceRays, kPipeRing pieces in flight on four streams, so that the staging copy
 // of piece q+1, the H2D copy + kernel of piece q and the D2H copy of piece q-1 overlap.  Pageable caller memory is
 // staged through pinned buffers by a few host threads; pinned memory (rt_host_alloc / hipHostMalloc) is read and written
 // by DMA directly.
@@ -966,14 +973,23 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
             const uint64_t m = count(q);
             const rt_ray* src = rays + first(q);
             if (stage_in) { p.pool->copy(p.pin_in[k], src, m * sizeof(rt_ray)); src = static_cast<const rt_ray*>(p.pin_in[k]); }
-            hipStream_t st = p.st[q & 1];
-            RT_HIP_SLOT(r, hipMemcpyAsync(p.d_in[k], src, m * sizeof(rt_ray), hipMemcpyHostToDevice, st));
+            void* dst = stage_out ? p.pin_out[k] : static_cast<void*>(static_cast<char*>(out) + first(q) * osz);
+            // One stream per direction and two for the kernels (even / odd pieces), chained by events: the inbound copies follow
+            // one another without waiting for anything but their ring slot, and the kernels of neighbouring pieces may overlap
+            // (small launches have tails; the 10 M-triangle soup is kernel-bound here).  (Pieces alternating over two streams,
+            // each with H2D | kernels | D2H, reached 65 % of the link rate from pinned memory: copies of both directions queued
+            // on one stream do not overlap with the other stream's.  Now 86-89 %: profiles/r03t_host_path.txt.)
+            hipStream_t s_in = p.st[0], s_out = p.st[1], s_k = p.st[2 + (q & 1)];
+            RT_HIP_SLOT(r, hipMemcpyAsync(p.d_in[k], src, m * sizeof(rt_ray), hipMemcpyHostToDevice, s_in));
+            RT_HIP_SLOT(r, hipEventRecord(p.got[k], s_in));
+            RT_HIP_SLOT(r, hipStreamWaitEvent(s_k, p.got[k], 0));
             RT_HIP_SLOT(r, trace_rays(c, r, any_hit, false, static_cast<const rt_ray*>(p.d_in[k]), m,
                                       any_hit ? nullptr : static_cast<rt_hit*>(p.d_out[k]),
-                                      any_hit ? static_cast<uint8_t*>(p.d_out[k]) : nullptr, st));
-            void* dst = stage_out ? p.pin_out[k] : static_cast<void*>(static_cast<char*>(out) + first(q) * osz);
-            RT_HIP_SLOT(r, hipMemcpyAsync(dst, p.d_out[k], m * osz, hipMemcpyDeviceToHost, st));
-            RT_HIP_SLOT(r, hipEventRecord(p.done[k], st));
+                                      any_hit ? static_cast<uint8_t*>(p.d_out[k]) : nullptr, s_k));
+            RT_HIP_SLOT(r, hipEventRecord(p.ran[k], s_k));
+            RT_HIP_SLOT(r, hipStreamWaitEvent(s_out, p.ran[k], 0));
+            RT_HIP_SLOT(r, hipMemcpyAsync(dst, p.d_out[k], m * osz, hipMemcpyDeviceToHost, s_out));
+            RT_HIP_SLOT(r, hipEventRecord(p.done[k], s_out));
         }
         for (uint64_t q = n_pieces > (uint64_t)kPipeRing ? n_pieces - kPipeRing : 0; q < n_pieces; ++q)
             if ((rc = finish(q)) != RT_OK) return rc;

@@ -196,7 +196,7 @@ def c4(n_tris, n_rays):
                          "same_as_bvh2": bool(hits.cpu().numpy().view(rt.HIT).tobytes() == keep["bvh2"].tobytes())}
         r.set_option(rt.OPT_RAY_BINNING, 2)
         mh = min(n_rays, 1 << 25)
-        hp = {"rays": mh, "note": "rt_trace: host rays in + kernels + host hits out, 2 Mi-ray pieces on two streams; pinned = rt_host_alloc "
+        hp = {"rays": mh, "note": "rt_trace: host rays in + kernels + host hits out, 2 Mi-ray pieces, copies and kernels on their own streams; pinned = rt_host_alloc "
                                   "blocks (DMA direct), pageable = staged through pinned buffers by host threads"}
         p_rays, p_hits = r.host_alloc(mh, rt.RAY), r.host_alloc(mh, rt.HIT)
         p_rays[:] = rays_np[:mh]
