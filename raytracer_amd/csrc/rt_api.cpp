@@ -953,7 +953,11 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
         Replica& r = c->reps[s];
         const uint64_t b = std::min(per * s, n), e = std::min(b + per, n);
         if (e <= b) return RT_OK;
-        const uint64_t piece = std::min<uint64_t>(kPieceRays, e - b);
+        // 2 Mi-ray pieces keep the link busy when the kernels are fast; structures that do not fit the L2s (the ones whose rays get
+        // binned) run small launches at well under their resident rate, so their pieces are twice as long (10 M-triangle soup:
+        // 1.03 -> 1.16 Grays/s; the bench scene would lose 3 %: profiles/r03t_host_path.txt)
+        const uint64_t scene_bytes = (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48;
+        const uint64_t piece = std::min<uint64_t>(scene_bytes > kBinMinSceneBytes ? 2 * kPieceRays : kPieceRays, e - b);
         RT_HIP_SLOT(r, hipSetDevice(r.device));
         int rc = pipe_prepare(r, piece, stage_in, stage_out, osz);
         if (rc != RT_OK) return rc;
