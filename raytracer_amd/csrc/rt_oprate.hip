@@ -47,6 +47,9 @@ KERNEL(k_cndm2,  "v_cndmask_b32 %0, %1, %2, vcc", "v"(a), "v"(b))               
 KERNEL(k_subf,   "v_sub_f32 %0, %0, %1", "v"(a))
 KERNEL(k_xor,    "v_xor_b32 %0, %0, %1", "v"(a))
 KERNEL(k_or3,    "v_or3_b32 %0, %0, %1, %2", "v"(a), "v"(b))
+KERNEL(k_orsdwa, "v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2", "v"(a))   // magic | byte 2: the integer half of a conversion
+KERNEL(k_addsdwa,"v_add_f32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v"(a))
+KERNEL(k_andsdwa,"v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3", "v"(a))
 // same, with a clobber list (instructions that write or read a named SGPR pair) and a per-step instruction count
 #define KERNEL_C(NAME, ASM, CLOB, ...) \
 __global__ __launch_bounds__(256) void NAME(float* out, float a, float b) { \
@@ -77,7 +80,7 @@ int main() {
         {"v_cndmask_b32", k_cndm}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_cmp_lt_f32", k_cmp}, {"v_cvt_pkrtz", k_cvtpk}, {"cvt_ubyte_sdwa", k_sdwa},
         {"v_fma_mix_f32", k_fmamix}, {"v_pk_min_u16", k_pkminu}, {"v_ldexp_f32", k_ldexp}, {"v_and_or_b32", k_andor},
         {"v_lshl_or_b32", k_lshlor}, {"v_alignbit_b32", k_align}, {"v_mad_u32_u24", k_madu24}, {"v_med3_f32", k_med3}, {"v_cvt_f32_f16", k_cvtf16},
-        {"v_bfi_b32", k_bfi}, {"v_cmp_lt_u32", k_cmpu}, {"v_cndmask(no chain)", k_cndm2}, {"v_sub_f32", k_subf}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3},
+        {"v_bfi_b32", k_bfi}, {"v_cmp_lt_u32", k_cmpu}, {"v_cndmask(no chain)", k_cndm2}, {"v_sub_f32", k_subf}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3}, {"v_or_b32_sdwa byte", k_orsdwa}, {"v_add_f32_sdwa byte", k_addsdwa}, {"v_and_b32_sdwa byte", k_andsdwa},
         {"v_cndmask sgpr pair", k_cndm_s}, {"cndmask+fma (x2)", k_cndm_fma}, {"cndmask+3fma (x4)", k_cndm_3fma}, {"v_cmp -> sgpr pair", k_cmp_s},
         {"v_cmp+v_cndmask (x2)", k_cmp_cndm}, {"v_ashrrev_i32", k_ashr}, {"v_max_i32", k_maxi}, {"v_or_b32", k_or},
         {"v_readfirstlane", k_readlane}, {"v_cndmask -1 literal", k_cndm_lit} };
