@@ -249,7 +249,11 @@ int  rt_resolve_dev(rt_ctx* ctx, int slot, const float* d_radiance4, uint64_t n_
 /* Last segment of the path loop + resolve in one launch: rt_shade_stripes_dev(..., d_out = NULL) followed by
  * rt_resolve_dev (frag.glsl:310-338, :357-359) without the final radiance going through HBM.  n = pixels * spp rays in
  * (pixel, sample) order.  d_radiance4 is read but NOT updated (with spp not a power of two <= 64 the two separate
- * kernels run instead and it is).  Same bits as the two calls. */
+ * kernels run instead and it is).  Same bits as the two calls.
+ * Precondition: the hit record of a dead ray (tmax <= tmin) is a miss (prim = RT_MISS) -- what every trace entry point of
+ * this library writes for such a ray.  Without lights the kernel does not read the rays at all (48 instead of 80 bytes per
+ * path) and decides from the hit record alone; a dead ray paired with a stale non-miss record would add that record's
+ * emission. */
 int  rt_shade_resolve_dev(rt_ctx* ctx, int slot, const rt_ray* d_rays, const rt_hit* d_hits, uint64_t n, uint32_t spp,
                           float* d_throughput4, float* d_radiance4, float* d_linear4, uint8_t* d_rgba8, void* stream);
 /* The whole of frag.glsl:main for a w x h frame: spp jittered samples per pixel (the reference: 10), `bounces`

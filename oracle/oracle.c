@@ -2,7 +2,7 @@
  * oracle.c -- plain-C CPU restatement of the reference hot path.  TEST INFRASTRUCTURE: see oracle.h.
  *
  * Canonical arithmetic (fp32, compile with -ffp-contract=off; the HIP kernels implement the same
- * order independently in raytracer_amd/csrc/rt_device.h):
+ * order independently in raytracer_amd/csrc/kernels.hip):
  *   dot(a,b)    = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
  *   cross(a,b)  = ( fma(a.y,b.z, -(a.z*b.y)), fma(a.z,b.x, -(a.x*b.z)), fma(a.x,b.y, -(a.y*b.x)) )
  *   normalize v = v / sqrt(dot(v,v))            (three IEEE divisions)

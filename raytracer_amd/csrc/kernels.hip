@@ -883,8 +883,10 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
     const uint32_t mid = (prim & RT_SPHERE_BIT) ? s.sphere_mat[prim & ~RT_SPHERE_BIT]
                                                 : __float_as_uint(s.normals[(size_t)prim * 3].w);
     const Mat m = load_mat(s, mid);
-    C = mk(__fmaf_rn(T.x * m.emission.x, m.strength, C.x), __fmaf_rn(T.y * m.emission.y, m.strength, C.y),
-           __fmaf_rn(T.z * m.emission.z, m.strength, C.z));                         // :313
+    // lanes that only follow the packet (PACKET && !ok: no path, or a path that missed) read primitive 0's material as a
+    // placeholder and must not add its emission: their radiance stays as it is, as on the early-return paths above
+    if (ok) C = mk(__fmaf_rn(T.x * m.emission.x, m.strength, C.x), __fmaf_rn(T.y * m.emission.y, m.strength, C.y),
+                   __fmaf_rn(T.z * m.emission.z, m.strength, C.z));                 // :313
     f3 V = norm3(mk(-d.x, -d.y, -d.z));                                             // :316
     for (uint32_t li = 0; li < s.n_lights; ++li) {                                  // :319-338
         float4 l0 = s.lights[2 * li], l1 = s.lights[2 * li + 1];

@@ -898,12 +898,12 @@ static bool is_pinned(const void* p) {
 
 static int pipe_prepare(Replica& r, uint64_t piece, bool stage_in, bool stage_out, size_t osz) {
     HostPipe& p = r.pipe;
-    if (!p.ready) {
-        for (int k = 0; k < 4; ++k) RT_HIP_SLOT(r, hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking));
+    if (!p.ready) {                                 // a call that failed part-way left some handles behind: create only the missing ones
+        for (int k = 0; k < 4; ++k) if (!p.st[k]) RT_HIP_SLOT(r, hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking));
         for (int k = 0; k < kPipeRing; ++k) {
-            RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.done[k], hipEventDisableTiming));
-            RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.got[k], hipEventDisableTiming));
-            RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.ran[k], hipEventDisableTiming));
+            if (!p.done[k]) RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.done[k], hipEventDisableTiming));
+            if (!p.got[k]) RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.got[k], hipEventDisableTiming));
+            if (!p.ran[k]) RT_HIP_SLOT(r, hipEventCreateWithFlags(&p.ran[k], hipEventDisableTiming));
         }
         p.ready = true;
     }
@@ -962,6 +962,13 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
         int rc = pipe_prepare(r, piece, stage_in, stage_out, osz);
         if (rc != RT_OK) return rc;
         HostPipe& p = r.pipe;
+        // Whatever way the loop below is left, no copy may outlive the call: earlier pieces still read the caller's rays (or
+        // pin_in) and write the caller's `out` (or pin_out), and the next call reuses the ring.  On success every piece has
+        // been waited for already; on an error return the four streams are drained first.
+        struct Drain {
+            HostPipe& p; bool armed = true;
+            ~Drain() { if (armed) for (hipStream_t s : p.st) if (s) (void)hipStreamSynchronize(s); }
+        } drain{ p };
         const uint64_t n_pieces = (e - b + piece - 1) / piece;
         auto first = [&](uint64_t q) { return b + q * piece; };
         auto count = [&](uint64_t q) { return std::min(piece, e - first(q)); };
@@ -997,6 +1004,7 @@ static int trace_host(rt_ctx* c, const rt_ray* rays, uint64_t n, void* out, bool
         }
         for (uint64_t q = n_pieces > (uint64_t)kPipeRing ? n_pieces - kPipeRing : 0; q < n_pieces; ++q)
             if ((rc = finish(q)) != RT_OK) return rc;
+        drain.armed = false;
         return RT_OK;
     });
 }

@@ -159,8 +159,7 @@ extern "C" int rt_bvh_build_host(const void* tris, uint32_t n_tris, uint32_t tri
     *stats = rt_scene_stats{};
     stats->n_tris = n_tris; stats->sah_cost = hs.sah_cost; stats->node_bytes = 64; stats->tri_bytes = 48;
     stats->n_nodes = hs.n_nodes; stats->n_leaves = hs.n_leaves; stats->max_depth = hs.depth;
-    if (layout == 3) stats->n_lights = hs.stack_need;      // host-only entry: reports the 4-wide stack bound here
-    stats->stack_entries = hs.stack_need + 2;
+    stats->stack_entries = hs.stack_need + 2;              // the traversal-stack bound (pushes + sentinel + spare)
     stats->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     stats->device_bytes = (uint64_t)hs.nodes.size() * 4 + (uint64_t)n_tris * 96;
     if (nodes_out) {

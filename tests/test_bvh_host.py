@@ -77,7 +77,8 @@ def check_tree(tris, layout, max_leaf=4):
         assert (seen == 1).all()
         assert len(visited_nodes) == stats["n_nodes"]
         if layout == rt.TRAVERSAL_BVH4Q:
-            assert max_stack <= stats["n_lights"], "reported stack bound must cover the tree"   # host entry reports it here
+            assert max_stack <= stats["stack_entries"] - 2, "reported stack bound must cover the tree"
+            assert stats["n_lights"] == 0
     return stats
 
 
@@ -114,7 +115,7 @@ def test_depth_is_bounded_for_adversarial_input():
     st = check_tree(t, rt.TRAVERSAL_BVH2)
     assert st["max_depth"] <= 30
     st4 = check_tree(t, rt.TRAVERSAL_BVH4Q)
-    assert st4["n_lights"] + 2 <= 64
+    assert st4["stack_entries"] <= 64
 
 
 def test_build_is_deterministic_across_thread_counts():

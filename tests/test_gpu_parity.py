@@ -718,6 +718,66 @@ def test_fused_primary_shade_equals_the_three_separate_stages(renderer, torch_de
         assert (not with_lights) or float(rad.view(-1, 4)[:, :3].sum()) > 0
 
 
+def _open_scene_emissive_first():
+    """A floor and a floating panel under open sky: most primary rays of the default camera miss.  Triangle 0 is an
+    EMITTER, so a lane that only follows the packet and reads primitive 0 as a placeholder would show."""
+    t = np.zeros(6, dtype=rt.TRIANGLE)
+    quads = [((-0.6, 0.3, 1.6), (0.6, 0.3, 1.6), (0.6, -0.3, 1.6), (-0.6, -0.3, 1.6)),       # panel (emissive), tris 0-1
+             ((-2.0, 2.0, 0.0), (2.0, 2.0, 0.0), (2.0, -2.0, 0.0), (-2.0, -2.0, 0.0)),        # floor, tris 2-3
+             ((-0.4, -1.0, 0.2), (0.4, -1.0, 0.2), (0.4, -1.0, 1.0), (-0.4, -1.0, 1.0))]      # small wall, tris 4-5
+    for q, (a, b, c, d) in enumerate(quads):
+        for k, (p0, p1, p2) in enumerate(((a, b, c), (a, c, d))):
+            tri = t[2 * q + k]
+            e1, e2 = np.subtract(p1, p0), np.subtract(p2, p0)
+            nrm = np.cross(e1, e2); nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+            for name, p in (("v0", p0), ("v1", p1), ("v2", p2)):
+                tri[name]["position"], tri[name]["normal"] = p, nrm
+            tri["material"]["albedo"] = (0.8, 0.7, 0.6)
+            tri["material"]["roughness"], tri["material"]["metallic"] = 0.6, 0.1
+            if q == 0:
+                tri["material"]["emission"], tri["material"]["emissionStrength"] = (1.0, 0.9, 0.8), 3.0
+    return t
+
+
+@pytest.mark.parametrize("mode", [rt.TRAVERSAL_BVH2, rt.TRAVERSAL_BVH4Q])
+def test_fused_primary_shade_leaves_missing_rays_dark_when_triangle_0_emits(renderer, torch_dev, mode):
+    """Open scene, point lights, emissive triangle 0: the fused packet kernel (BVH4Q) keeps its missing lanes in the wave
+    for the shadow walk; they must not pick up primitive 0's emission.  Fused = separate stages = oracle, bit for bit."""
+    torch = torch_dev
+    tris, lights = _open_scene_emissive_first(), _lights2()
+    cam = rt.default_camera(48 / 32)
+    renderer.set_option(rt.OPT_TRAVERSAL, mode)
+    renderer.create_data(tris, None, lights)
+    renderer.update_camera(cam)
+    w, h, spp, seed = 48, 32, 4, 3
+    n = w * h * spp
+    s = torch.cuda.current_stream()
+    f = lambda k: torch.full((n * k,), 7.0, dtype=torch.float32, device="cuda")
+    ra, hits, thr, rad, nxt = f(8), f(4), f(4), f(4), f(8)
+    renderer.path_init_dev(n, thr, rad, stream=s)
+    renderer.trace_primary_dev(w, h, hits, ra, spp=spp, seed=seed, jitter=True, stream=s)
+    renderer.shade_dev(ra, hits, n, thr, rad, nxt, key0=0, seed=seed + 1, stream=s)
+    thr2, rad2, nxt2 = f(4), f(4), f(8)
+    renderer.primary_shade_stripes_dev(w, h, 0, h, h, 1, thr2, rad2, nxt2, spp=spp, seed=seed, jitter=True,
+                                       shade_seed=seed + 1, stream=s)
+    torch.cuda.synchronize()
+    g_hits = to_np(hits, rt.HIT)
+    missed = g_hits["prim"] == rt.MISS
+    assert 0.2 < missed.mean() < 0.95, "the scene is meant to be open"
+    r2 = rad2.cpu().numpy().reshape(-1, 4)
+    assert not r2[missed, :3].any(), "a ray that misses carries no radiance (frag.glsl:351-353)"
+    for a, b, what in ((thr, thr2, "throughput"), (rad, rad2, "radiance"), (nxt, nxt2, "next rays")):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), what
+    sc = oracle.Scene(tris, None, lights)
+    o_rays = oracle.primary_rays(cam, w, h, spp=spp, seed=seed, jitter=True)
+    o_hits = oracle.trace(sc, o_rays)
+    assert_parity(g_hits, o_hits, "primary hits")
+    o_thr = np.ones((n, 4), dtype=np.float32); o_thr[:, 3] = 0
+    o_rad = np.zeros((n, 4), dtype=np.float32)
+    oracle.shade(sc, o_rays, o_hits, o_thr, o_rad, key0=0, seed=seed + 1)
+    assert rad2.cpu().numpy().tobytes() == o_rad.tobytes() and o_rad[:, :3].sum() > 0
+
+
 @pytest.mark.parametrize("with_lights", [False, True])
 @pytest.mark.parametrize("spp", [1, 3, 4, 16])
 def test_fused_last_segment_resolve_equals_the_two_stages(renderer, torch_dev, spp, with_lights):
@@ -858,7 +918,7 @@ def test_big_soup_takes_the_auto_paths_and_matches_the_reference_loop(big_soup, 
         st = r.create_data(tris)
         assert st["n_nodes"] * 64 + st["n_tris"] * 48 > 48 << 20, "scene too small to trigger auto ray binning"
         assert st["sah_cost"] > 250.0, "tree too coherent to trigger the ray-buffer primary path"
-        assert hstats["n_lights"] + 2 > 20, "stack bound too small to trigger the capped LDS stack"
+        assert hstats["stack_entries"] > 20, "stack bound too small to trigger the capped LDS stack"
         d_rays = to_dev(torch, rays)
         hits, occ = dev_buf(torch, n, 16), torch.zeros(n, dtype=torch.uint8, device="cuda")
         r.trace_dev(d_rays, n, hits)
