@@ -19,6 +19,7 @@ per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or run 
 environment it starts the N ranks itself, as a torch.distributed.run child process, before anything touches the GPU.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -131,8 +132,12 @@ def main():
     rays, brays = f32(n_local * 8), f32(n_local * 8)
     phits, bhits = f32(n_local * 4), f32(n_local * 4)
     thr, rad = f32(n_local * 4), f32(n_local * 4)
-    fb = torch.empty(n_px, dtype=torch.int32, device=dev)            # RGBA8 framebuffer stripes of this rank
+    # RGBA8 framebuffer stripes of this rank; two of them for N > 1, so that the gather of frame k can run while frame k + 1
+    # is traced into the other one
+    fbs = [torch.empty(n_px, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
     gidx = rd.gather_index(plan, dev) if world > 1 else None
+    state = {"k": 0, "ticket": None, "frame": None}
+    cur_fb = lambda: fbs[state["k"] % len(fbs)]
     stream = torch.cuda.current_stream()
     row_len = W * SPP
     key0 = plan.y0 * row_len                                         # RNG key = path index in the full frame
@@ -153,28 +158,45 @@ def main():
 
     def stage_shade2_resolve():
         # radiance of the second (last) segment + resolve in one launch: the final radiance stays in registers
-        r.shade_resolve_dev(brays, bhits, n_local, SPP, thr, rad, None, fb, stream=stream)
+        r.shade_resolve_dev(brays, bhits, n_local, SPP, thr, rad, None, cur_fb(), stream=stream)
 
     gather_all = os.environ.get("RT_BENCH_GATHER", "root") == "all"          # "all": every rank gets the frame (all-gather)
+    # RCCL, gather to rank 0: the exchange of frame k is asynchronous (RCCL's own stream) and overlaps the kernels of frame
+    # k + 1; frame k is complete on rank 0 -- waited for and de-interleaved -- by the end of step k + 1, the last one by the
+    # drain inside the timed region.  RT_BENCH_GATHER_SYNC=1 keeps the blocking form for A/B runs.
+    pipelined = world > 1 and backend == "nccl" and not gather_all and os.environ.get("RT_BENCH_GATHER_SYNC") != "1"
+    fg = rd.FrameGather(plan, (W,), torch.int32, dev, 0, gidx) if pipelined else None
 
     def stage_gather():
         # per-rank RGBA8 stripes -> the frame on rank 0 (what shows it): each rank sends its 4 MB once, over its own
         # xGMI link to rank 0 (RCCL send/recv), and rank 0 de-interleaves the stripes with one index_select
         if world == 1:
-            return fb
-        mine = fb.view(plan.padded_rows, W)
+            state["frame"] = cur_fb()
+            return
+        mine = cur_fb().view(plan.padded_rows, W)
+        if pipelined:
+            ticket = fg.start(mine)
+            if state["ticket"] is not None:
+                state["frame"] = fg.finish(state["ticket"])
+            state["ticket"] = ticket
+            return
         if backend != "nccl":                                                    # rehearsal: stage through the host
             mine, idx = mine.cpu(), gidx.cpu()
         else:
             idx = gidx
-        return rd.gather_rows(mine, plan, idx) if gather_all else rd.gather_rows_to(mine, plan, 0, idx)
+        state["frame"] = rd.gather_rows(mine, plan, idx) if gather_all else rd.gather_rows_to(mine, plan, 0, idx)
+
+    def drain():
+        if state["ticket"] is not None:
+            state["frame"] = fg.finish(state["ticket"])
+            state["ticket"] = None
 
     stages = [stage_primary_shade, stage_bounce_trace, stage_shade2_resolve, stage_gather]
 
     def step():
         for st in stages:
-            out = st()
-        return out
+            st()
+        state["k"] += 1
 
     # ---- instrumented pass: B, N, T per ray (same kernels with counters on) --------------------------
     r.set_option(rt.OPT_COUNTERS, 1)
@@ -188,6 +210,7 @@ def main():
     # ---- warmup, then exactly K timed steps ------------------------------------------------------------
     for _ in range(args.warmup):
         step()
+    drain()
     ne = len(stages) + 1
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(ne)] for _ in range(args.steps)]
     if world > 1:
@@ -199,6 +222,8 @@ def main():
         for j, st in enumerate(stages):
             st()
             ev[k][j + 1].record(stream)
+        state["k"] += 1
+    drain()                                              # the last frame's gather + de-interleave belong to the K steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -211,14 +236,15 @@ def main():
     ms = [float(np.mean([ev[k][j].elapsed_time(ev[k][j + 1]) for k in range(args.steps)])) for j in range(len(stages))]
     ms_primary, ms_btrace, ms_shade2, ms_gather = ms
 
-    frame = step()                                       # one more (untimed) frame for the checksum below
+    step()                                               # one more (untimed) frame for the checksum below
+    drain()
+    frame = state["frame"]
     unfused_primary()                                    # primary rays / hits in HBM for the parity sample
     torch.cuda.synchronize()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    import hashlib
     frame_np = frame.reshape(-1)[: W * H].cpu().numpy()
     frame_sha = hashlib.sha256(frame_np.tobytes()).hexdigest()
     lit_pixels = int((frame_np.view("uint32") & 0xFFFFFF != 0).sum())       # the hash says something only if the frame is not black
@@ -231,11 +257,20 @@ def main():
     # dominant kernel = the incoherent bounce closest-hit launch (k_trace_strip)
     ach_tflops = fl_b * live_b / (ms_btrace * 1e-3) / 1e12
     ach_gbs = by_b * live_b / (ms_btrace * 1e-3) / 1e9
-    pmc = {}
+    # Hardware counters cannot be read inside this process: `traffic` and the measured_* fields are PASTED from the last
+    # rocprofv3 --pmc passes over this same command (scripts/profile_round.sh -> profiles/pmc_latest.json).  The file names
+    # the kernels.hip it was measured on; if that is not the source this tree holds, the fields are null, not stale.
+    pmc, pmc_src = {}, {"pmc_source": None, "pmc_tag": None, "pmc_matches_kernel_sources": None}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path) and world == 1:
         try:
             pmc = json.load(open(pmc_path))
+            ksha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "raytracer_amd", "csrc", f), "rb").read() for f in ("kernels.hip", "kernels.hpp", "Makefile"))).hexdigest()
+            ok = pmc.get("kernel_sources_sha256") == ksha
+            pmc_src = {"pmc_source": "profiles/pmc_latest.json (rocprofv3 --pmc passes of this command, separate run)",
+                       "pmc_tag": pmc.get("tag"), "pmc_matches_kernel_sources": bool(ok)}
+            if not ok:
+                pmc = {}
         except Exception:
             pmc = {}
     kname = "k_trace_strip<%s> (bounce closest-hit)" % ("bvh4q" if args.traversal == 3 else "bvh2")
@@ -249,7 +284,7 @@ def main():
                 "launch_ms": round(ms_btrace, 4), "rays_per_launch": int(live_b),
                 "measured_valu_busy_pct": pmc.get("k_trace_valu_busy_pct"),
                 "measured_valu_inst_per_simd_cycle": pmc.get("k_trace_valu_inst_per_simd_cycle"),
-                "measured_lane_utilisation_pct": pmc.get("k_trace_lane_utilisation_pct"),
+                "measured_lane_utilisation_pct": pmc.get("k_trace_lane_utilisation_pct"), **pmc_src,
                 "note": "SURVEY 8d flop count (24 per box test, 53 per triangle test) over the HIP-event launch time; "
                         "never MFMA.  Most issued VALU instructions are converts/compares/selects, so the issue-slot "
                         "utilisation is measured_valu_busy_pct x measured_lane_utilisation_pct (rocprofv3, profiles/)"}
@@ -275,7 +310,8 @@ def main():
         "frame_lit_pixels": lit_pixels,
         "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
                   "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
-                  "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0")},
+                  "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0"),
+                  "exchange_overlaps_next_frame": bool(pipelined)},
         # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints
         # (the packet form of the tile kernel keeps its stack in a register: no LDS)
         "launch": {"dynamic_lds_bytes_per_block": {"k_primary_packet": 0,

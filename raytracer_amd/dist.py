@@ -116,6 +116,47 @@ def gather_rows_to(local, plan, dst=0, index=None, group=None):
     return full.index_select(0, index)
 
 
+class FrameGather:
+    """gather_rows_to split in two, so that the exchange of frame k runs while frame k+1 is being traced.
+
+    start(local) issues the gather as an asynchronous collective (on the "nccl" backend RCCL runs it on its own stream,
+    behind everything already queued on the current stream) and returns a ticket at once; finish(ticket) makes the current
+    stream wait for it and de-interleaves on rank `dst`.  Two receive buffers alternate, and the caller alternates two
+    `local` buffers the same way: buffer k % 2 may be written again once finish() of frame k has been CALLED (stream
+    order does the rest).  The intended order per frame: start(k), finish(k - 1), then the kernels of frame k + 1."""
+
+    def __init__(self, plan, row_shape, dtype, device, dst=0, index=None, group=None):
+        self.plan, self.dst, self.group = plan, dst, group
+        self.index = gather_index(plan, device) if index is None else index
+        self.collective = not (plan.world == 1 and not _group_up())
+        self.full = [None, None]
+        if self.collective and plan.rank == dst:
+            shape = (plan.world * plan.padded_rows,) + tuple(row_shape)
+            self.full = [torch.empty(shape, dtype=dtype, device=device) for _ in range(2)]
+        self.k = 0
+
+    def start(self, local):
+        if local.shape[0] != self.plan.padded_rows:
+            raise ValueError(f"local buffer has {local.shape[0]} rows, plan needs {self.plan.padded_rows}")
+        work, full = None, local
+        if self.collective:
+            local = local.contiguous()
+            full = self.full[self.k % 2]
+            parts = list(full.chunk(self.plan.world, dim=0)) if self.plan.rank == self.dst else None
+            work = dist.gather(local, parts, dst=self.dst, group=self.group, async_op=True)
+        self.k += 1
+        return (work, full)
+
+    def finish(self, ticket):
+        """-> [h, row_elems...] on rank dst, None elsewhere."""
+        work, full = ticket
+        if work is not None:
+            work.wait()                              # device tensors: the current stream waits, the host does not
+        if self.plan.rank != self.dst:
+            return None
+        return full.index_select(0, self.index)
+
+
 def shard_range(n, world, rank):
     """Contiguous range [first, first+count) of rank; every rank's padded count is ceil(n/world)."""
     per = (n + world - 1) // world

@@ -1,7 +1,7 @@
 """Runs the BASELINE.json configs C1..C5 on ONE MI355X and prints one JSON line per config (results table of
 DESIGN.md).  Parity gates (prim-ID mismatches against the oracle / the brute-force HIP kernel) ride along.
 
-usage: python scripts/run_configs.py [c1 c2 c3 c3b c4 c5] [--soup N] [--rays N]
+usage: python scripts/run_configs.py [c0 c1 c2 c3 c3b c4 c5] [--soup N] [--rays N]
 """
 import argparse
 import json
@@ -51,6 +51,37 @@ def sample_parity(tris, sph, rays_np, hits_np, k, seed=0):
 
 def out(d):
     print(json.dumps(d), flush=True)
+
+
+def c0():
+    """The reference's own frame: the Cornell box of VkRenderer.cpp:171-250 in its window (1200x1000, globals.h:12-13) at the
+    shader's SAMPLES 10 / BOUNCES 8 (frag.glsl:3-4) through rt_render, host RGBA8 out -- the workload behind the ms/frame (FPS)
+    text the reference shows (VkRenderer.cpp:1405).  Beside it the oracle's frame on all host cores, and a gate at a tenth of
+    the size: RGBA8 within 1 LSB of orc_render (device powf vs libm powf; the linear frame is bit-exact, tests/)."""
+    tris, sph, _ = scenes.cornell()
+    w, h, spp, bounces = 1200, 1000, 10, 8
+    cam = rt.default_camera(w / h)
+    res = {"config": f"C0 reference frame: Cornell 12 tris + 3 spheres, {w}x{h}, {spp} spp x {bounces} bounces, rt_render -> host RGBA8"}
+    with rt.Renderer((0,)) as r:
+        r.create_data(tris, sph); r.update_camera(cam)
+        r.render(w, h, spp, bounces, 1)
+        t = time.perf_counter(); K = 10
+        for k in range(K):
+            fr = r.render(w, h, spp, bounces, 1 + k)
+        ms = (time.perf_counter() - t) / K * 1e3
+        res.update({"ms_per_frame": round(ms, 3), "fps": round(1e3 / ms, 1), "path_segments_per_frame_max": w * h * spp * bounces,
+                    "mean_rgb": round(float(fr[..., :3].mean()), 2)})
+        sw, sh = w // 10, h // 10
+        got = r.render(sw, sh, spp, bounces, 3)
+        t = time.perf_counter()
+        _, want = oracle.render(oracle.Scene(tris, sph), rt.default_camera(sw / sh), sw, sh, spp, bounces, 3)
+        dt = time.perf_counter() - t
+        r.update_camera(rt.default_camera(sw / sh)); got = r.render(sw, sh, spp, bounces, 3)
+        res["gate"] = {"size": [sw, sh], "max_abs_rgba8_diff": int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max()),
+                       "identical_pixels_frac": round(float((got == want).all(axis=-1).mean()), 5)}
+        res["cpu_oracle"] = {"ms_per_frame_extrapolated": round(dt * 1e3 * (w * h) / (sw * sh), 1), "threads": oracle.num_threads(),
+                             "note": f"orc_render on {sw}x{sh} ({dt:.2f} s), scaled by the pixel ratio"}
+    out(res)
 
 
 def c1():
@@ -281,7 +312,7 @@ def main():
     ap.add_argument("--rays", type=int, default=64 * (1 << 20))
     a = ap.parse_args()
     for w in a.which:
-        {"c1": c1, "c2": c2, "c3": lambda: c3("sponza"), "c3b": lambda: c3("colonnade"), "c4": lambda: c4(a.soup, a.rays), "c5": lambda: c5(a.soup)}[w]()
+        {"c0": c0, "c1": c1, "c2": c2, "c3": lambda: c3("sponza"), "c3b": lambda: c3("colonnade"), "c4": lambda: c4(a.soup, a.rays), "c5": lambda: c5(a.soup)}[w]()
 
 
 if __name__ == "__main__":

@@ -132,7 +132,9 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
 cands = [d for k, d in out["kernels"].items() if k.startswith("k_trace") and "hbm_bytes" in d.get("derived", {})]
 kt = max(cands, key=lambda d: d.get("total_ms", 0.0)) if cands else None     # the bounce closest-hit launch
 if kt and "hbm_bytes" in kt.get("derived", {}):
-    json.dump({"tag": tag, "k_trace_hbm_bytes_per_launch": kt["derived"]["hbm_bytes"],
+    import hashlib
+    ksha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "raytracer_amd", "csrc", f), "rb").read() for f in ("kernels.hip", "kernels.hpp", "Makefile"))).hexdigest()
+    json.dump({"tag": tag, "kernel_sources_sha256": ksha, "k_trace_hbm_bytes_per_launch": kt["derived"]["hbm_bytes"],
                "k_trace_valu_busy_pct": kt["derived"].get("valu_busy_pct"),
                "k_trace_valu_inst_per_simd_cycle": kt["derived"].get("valu_inst_per_simd_cycle"),
                "k_trace_lane_utilisation_pct": kt["derived"].get("valu_lane_utilisation_pct"),

@@ -74,6 +74,20 @@ def _worker(rank, world, port, h, w, sh, n):
             assert (one is None) == (rank != dst)
             if rank == dst:
                 assert torch.equal(one, want)
+        # the pipelined form: the gather of frame k is in flight while frame k + 1 is written into the other buffer
+        fg = rd.FrameGather(p, (w, 4), torch.float32, "cpu", dst=world - 1)
+        bufs, prev, frames = [torch.empty_like(local), torch.empty_like(local)], None, []
+        for k in range(5):
+            bufs[k % 2].copy_(local + 100000.0 * k)
+            t = fg.start(bufs[k % 2])
+            if prev is not None:
+                frames.append(fg.finish(prev))
+            prev = t
+        frames.append(fg.finish(prev))
+        for k, f in enumerate(frames):
+            assert (f is None) == (rank != world - 1)
+            if f is not None:
+                assert torch.equal(f, want + 100000.0 * k), k
         # ray ranges
         first, cnt, per = rd.shard_range(n, world, rank)
         loc = torch.zeros(per, 4)

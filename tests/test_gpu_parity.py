@@ -1099,6 +1099,18 @@ for h, sh in ((37, 8), (64, 16)):
     b = rd.gather_rows(local, plan)
     assert a.is_cuda and b.is_cuda and a.shape == (h, 5)
     assert torch.equal(a, local[:h]) and torch.equal(b, local[:h])
+    # the pipelined form bench.py uses: the gather of frame k is in flight while frame k + 1 is produced
+    fg = rd.FrameGather(plan, (5,), torch.int32, "cuda")
+    bufs, prev, frames = [torch.empty_like(local), torch.empty_like(local)], None, []
+    for k in range(5):
+        bufs[k % 2].copy_(local + 1000 * k)
+        t = fg.start(bufs[k % 2])
+        if prev is not None: frames.append(fg.finish(prev))
+        prev = t
+    frames.append(fg.finish(prev))
+    torch.cuda.synchronize()
+    for k, f in enumerate(frames):
+        assert f.is_cuda and torch.equal(f, local[:h] + 1000 * k), k
 r = torch.arange(1000, dtype=torch.float32, device="cuda").view(250, 4)
 assert torch.equal(rd.gather_ranges(r, 240, 1), r[:240])
 dist.barrier(); torch.cuda.synchronize()
