@@ -84,6 +84,12 @@ enum {
                                the buffer walk the tree together as one packet, like the primary rays of the tile kernel.  Same hit records for any
                                buffer; faster only when consecutive rays really travel together (same region, similar
                                direction), slower -- possibly much -- when they do not.  Default 0. */
+    RT_OPT_FRAME_EXCHANGE = 16, /* contexts with several slots, rt_render / rt_trace_primary: how the slots' interleaved 8-row stripes
+                               reach slot 0's device, where they are put in image order and leave in ONE device-to-host copy.
+                               1 = RCCL: grouped ncclSend / ncclRecv, every slot over its own xGMI link to slot 0 (librccl.so.1 is
+                               loaded on first use; needs distinct device ordinals -- RCCL refuses a communicator with a GPU twice);
+                               2 = hipMemcpyPeerAsync (plain device copies when the ordinals repeat);
+                               0 auto (default) = 1 when all ordinals differ and RCCL loads, else 2.  Same frame in every case. */
     RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for
                                measuring what it protects against only: rays that start hundreds of scene extents away
                                then lose hits the reference loop finds (tests/test_gpu_parity.py, far-origin test). */
@@ -150,7 +156,7 @@ int  rt_scene_upload(rt_ctx* ctx,
 int  rt_scene_stats_get(const rt_ctx* ctx, rt_scene_stats* out);
 /* The host half of rt_scene_upload on its own (no device needed): BVH build + flatten.  layout 2 = BVH2 nodes,
  * 3 = BVH4q nodes (16 words per node, DESIGN.md "Data layout").  nodes_out / tri_order_out may be NULL (then only
- * the statistics are produced); for layout 3 stats->n_lights carries the traversal-stack bound. */
+ * the statistics are produced); stats->stack_entries carries the traversal-stack bound. */
 int  rt_bvh_build_host(const void* tris, uint32_t n_tris, uint32_t tri_stride, int layout, int max_leaf, int pad_log2,
                        int threads, rt_scene_stats* stats, uint32_t* nodes_out, uint64_t nodes_cap_words,
                        uint32_t* tri_order_out);
@@ -174,7 +180,8 @@ int  rt_host_free(rt_ctx* ctx, void* block);
  * pixel; uv = ((x+.5)/w, (y+.5)/h), row 0 = top (shaders/vert.glsl:9-12).  host_out[y*w+x]. */
 int  rt_trace_primary(rt_ctx* ctx, uint32_t w, uint32_t h, rt_hit* host_out);
 /* closest hit for caller-supplied rays (frag.glsl:265-301).  Rays are split in contiguous ranges
- * over the slots. */
+ * over the slots.  (rt_trace_primary and rt_render split the image rows instead: 8-row stripes dealt round-robin to the
+ * slots -- cost is spatially uneven, SURVEY.md 8e -- gathered on slot 0's device, RT_OPT_FRAME_EXCHANGE.) */
 int  rt_trace(rt_ctx* ctx, const rt_ray* host_rays, uint64_t n, rt_hit* host_out);
 /* any-hit: host_out[i] = 1 iff some primitive is hit with tmin <= t < tmax.  The reference has no
  * any-hit routine; its shadow query (frag.glsl:325-330) is rt_shadow_dev. */

@@ -41,6 +41,7 @@ assert RAY.itemsize == 32 and HIT.itemsize == 16
 OPT_TRAVERSAL, OPT_BVH_THREADS, OPT_COUNTERS, OPT_PAD_LOG2, OPT_MAX_LEAF, OPT_STRIP, OPT_REFILL, OPT_RAY_BINNING, OPT_LDS_STACK, OPT_PRIMARY, OPT_RAY_PAD = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 OPT_SAH_BINS, OPT_SAH_TRAV = 12, 13
 OPT_RAY_PACKETS = 15
+OPT_FRAME_EXCHANGE = 16
 NOALLOC_MAX_RAYS = 1 << 22
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
 TRAVERSAL_BVH = TRAVERSAL_BVH4Q

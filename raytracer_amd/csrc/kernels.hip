@@ -1278,6 +1278,16 @@ __global__ __launch_bounds__(kBlock) void k_fill(float4* __restrict__ d, uint64_
     if (i < n) d[i] = v;
 }
 
+// interleaved stripe shares -> image order (launch_gather_rows): one block row per image row, plain word copies
+__global__ __launch_bounds__(kBlock) void k_gather_rows(const uint32_t* __restrict__ stage, uint32_t* __restrict__ frame, uint32_t row_words,
+                                                        uint32_t stripe_h, uint32_t n_shares, uint32_t share_rows) {
+    const uint32_t y = blockIdx.y, stripe = y / stripe_h, share = stripe % n_shares;
+    const uint32_t local = (stripe / n_shares) * stripe_h + y % stripe_h;
+    const uint32_t* src = stage + ((size_t)share * share_rows + local) * row_words;
+    uint32_t* dst = frame + (size_t)y * row_words;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < row_words; i += gridDim.x * kBlock) dst[i] = src[i];
+}
+
 // ---- ray binning ------------------------------------------------------------------------------------------
 // Counting sort of ray INDICES by origin cell (kernels.hpp), four launches, no global atomics: per-block
 // histograms -> per-(block, bin) bases -> scatter with LDS cursors.  Rays of one bin keep no particular order.
@@ -1742,6 +1752,16 @@ hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t 
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, d, n, make_float4(x, y, z, w));
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const uint32_t* stage, uint32_t* frame, uint32_t h, uint32_t row_words, uint32_t stripe_h,
+                              uint32_t n_shares, uint32_t share_rows, hipStream_t st) {
+    if (h == 0 || row_words == 0) return hipSuccess;
+    if (!stage || !frame || stripe_h == 0 || n_shares == 0 || h > 65535u) return hipErrorInvalidValue;
+    if ((uint64_t)((h - 1) / stripe_h / n_shares + 1) * stripe_h > share_rows) return hipErrorInvalidValue;   // last row must lie inside its share
+    const uint32_t bx = std::min<uint32_t>(8u, (row_words + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_gather_rows, dim3(bx, h), dim3(kBlock), 0, st, stage, frame, row_words, stripe_h, n_shares, share_rows);
     return hipGetLastError();
 }
 

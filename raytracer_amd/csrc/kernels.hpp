@@ -118,6 +118,11 @@ hipError_t launch_shade_resolve(const DevScene& s, int mode, const rt_ray* d_ray
                                 uint32_t spp, const float4* d_throughput, const float4* d_radiance, float4* d_linear,
                                 uint32_t* d_rgba8, hipStream_t st);
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
+// Interleaved shares -> image order (multi-slot rt_render / rt_trace_primary): `stage` holds n_shares blocks of
+// share_rows rows x row_words 32-bit words; share s owns the stripes s, s + n_shares, ... of stripe_h rows each.
+// Row y of the h-row frame is row (y / stripe_h / n_shares) * stripe_h + y % stripe_h of share (y / stripe_h) % n_shares.
+hipError_t launch_gather_rows(const uint32_t* stage, uint32_t* frame, uint32_t h, uint32_t row_words, uint32_t stripe_h,
+                              uint32_t n_shares, uint32_t share_rows, hipStream_t st);
 
 constexpr int kStackDepth = 32;   // BVH2 depth budget + 2: bounds the per-lane traversal stack of the BVH2 layout
 constexpr int kWorkSlots = 4;     // chunk-cursor sets behind the counters: one per scratch slot of a replica (rt_api.cpp)

@@ -11,6 +11,8 @@
 #include "scene_host.hpp"
 
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>        // types and prototypes only: the library is loaded with dlopen on first use (Rccl below)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -132,6 +134,9 @@ struct Replica {
     hipEvent_t sc_ev[kNumScratchEvents] = {};
     bool sc_used[kNumScratchEvents] = {};
     void* d_noalloc = nullptr;         // this device's copy of the static scratch array of rt_trace_dev_noalloc
+    // multi-slot frames (rt_render / rt_trace_primary): slot 0 keeps the shares of all slots + the frame in image order here
+    void* d_gather = nullptr; size_t gather_cap = 0;
+    hipEvent_t ev_share = nullptr;     // "this slot's share is complete" (recorded on r.stream, waited for by slot 0's stream)
     HostPipe pipe;
     std::string err;
 };
@@ -148,6 +153,44 @@ double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
+
+// RCCL for the in-process frame gather (north_star: "framebuffer gathered over xGMI with RCCL").  Loaded on first use, so that
+// one-GPU users neither link nor load it; one communicator per slot, rank = slot, made by ncclCommInitAll.
+struct Rccl {
+    void* so = nullptr;
+    bool tried = false;
+    std::string why;                                   // why it cannot be used (after a failed attempt)
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::vector<ncclComm_t> comms;
+    bool load() {
+        if (tried) return so != nullptr;
+        tried = true;
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
+            if ((so = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!so) { const char* e = dlerror(); why = std::string("librccl.so.1 not loadable: ") + (e ? e : "?"); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(so, n); if (!p && why.empty()) why = std::string("RCCL symbol missing: ") + n; return p; };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!why.empty()) { dlclose(so); so = nullptr; return false; }
+        return true;
+    }
+    void destroy() {
+        for (ncclComm_t cm : comms) if (cm && CommDestroy) (void)CommDestroy(cm);
+        comms.clear();
+        // the library stays loaded: unloading RCCL while its proxy threads wind down is not worth the risk
+    }
+};
 
 }  // namespace
 
@@ -170,6 +213,9 @@ struct rt_ctx {
     int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
     int primary_path = 0;       // primary rays: 0 auto, 1 tile kernel (k_primary), 2 ray generation + ray-buffer kernel
     int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
+    int frame_exchange = 0;     // multi-slot frames: 0 auto, 1 RCCL send/recv, 2 peer copies (RT_OPT_FRAME_EXCHANGE)
+    Rccl rccl;
+    int last_exchange = 0;      // what the last multi-slot frame used (1 RCCL, 2 peer copies; 0 = none yet)
     BinGrid bin_grid{};         // 16^3 grid over the triangle bounds of the uploaded scene
     // scene
     bool has_scene = false, has_camera = false;
@@ -364,6 +410,132 @@ int slot_fail(Replica& r, hipError_t e, const char* what) {
 // Handler of every entry point's function-try-block: nothing is thrown across the ABI (abi_guard.hpp).
 #define RT_ABI_CATCH(ctx) catch (...) { rt_ctx* c__ = const_cast<rt_ctx*>(static_cast<const rt_ctx*>(ctx)); return abi_exception(c__ ? &c__->err : nullptr); }
 
+// ---- frames of contexts with several slots ---------------------------------------------------------------------------------
+// The image rows are dealt to the slots in interleaved stripes of kFrameStripe rows (cost is spatially uneven -- floor against
+// geometry -- so contiguous blocks would last as long as the slowest one).  Every slot fills a "share": its
+// stripes, compact, padded to the same number of rows on every slot.  The shares meet on slot 0's device, are put in image
+// order there (launch_gather_rows) and leave in one device-to-host copy.
+constexpr uint32_t kFrameStripe = 8;                 // rows per stripe: the tile height of the primary kernels
+struct FrameSplit {
+    uint32_t n_slots, share_rows;                    // rows of every slot's share (whole stripes, the last ones may be padding)
+    uint32_t y0(int s) const { return (uint32_t)s * kFrameStripe; }
+};
+FrameSplit frame_split(uint32_t h, int n_slots) {
+    const uint32_t n_stripes = (h + kFrameStripe - 1) / kFrameStripe;
+    return FrameSplit{ (uint32_t)n_slots, ((n_stripes + n_slots - 1) / n_slots) * kFrameStripe };
+}
+
+hipError_t grow(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);                       // hipFree waits for the device
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(p, need);
+    if (e == hipSuccess) *cap = need;
+    return e;
+}
+
+// slot 0's staging for a frame of h rows x row_bytes: [n_slots shares][frame in image order]; slot 0 writes its own share in
+// place.  (A context of one slot keeps room for a second copy of its share: the target of the RCCL self-send, frame_gather.)
+int frame_stage(rt_ctx* c, const FrameSplit& sp, uint32_t h, size_t row_bytes, char** shares, char** frame) {
+    Replica& r0 = c->reps[0];
+    const size_t share_bytes = (size_t)sp.share_rows * row_bytes;
+    const size_t blocks = sp.n_slots == 1 ? 2 : sp.n_slots;
+    RT_HIP(c, hipSetDevice(r0.device));
+    RT_HIP(c, grow(&r0.d_gather, &r0.gather_cap, share_bytes * blocks + (size_t)h * row_bytes));
+    *shares = static_cast<char*>(r0.d_gather);
+    *frame = *shares + share_bytes * blocks;
+    return RT_OK;
+}
+
+bool distinct_devices(const rt_ctx* c) {
+    for (size_t a = 0; a < c->reps.size(); ++a)
+        for (size_t b = a + 1; b < c->reps.size(); ++b)
+            if (c->reps[a].device == c->reps[b].device) return false;
+    return true;
+}
+
+int rccl_fail(rt_ctx* c, ncclResult_t e, const char* what) {
+    return fail(c, RT_E_DEVICE, std::string(what) + ": " + (c->rccl.GetErrorString ? c->rccl.GetErrorString(e) : "RCCL error"));
+}
+#define RT_RCCL(ctx, call)                                             \
+    do {                                                               \
+        ncclResult_t e__ = (call);                                     \
+        if (e__ != ncclSuccess) return rccl_fail((ctx), e__, #call);   \
+    } while (0)
+
+// one communicator per slot (rank = slot) over the context's devices
+int rccl_prepare(rt_ctx* c) {
+    Rccl& rc = c->rccl;
+    if (!rc.comms.empty()) return RT_OK;
+    if (!distinct_devices(c)) return fail(c, RT_E_INVALID, "RT_OPT_FRAME_EXCHANGE 1 (RCCL) needs distinct device ordinals: a communicator cannot hold one GPU twice");
+    if (!rc.load()) return fail(c, RT_E_DEVICE, rc.why);
+    std::vector<int> devs;
+    for (const Replica& r : c->reps) devs.push_back(r.device);
+    std::vector<ncclComm_t> comms(devs.size(), nullptr);
+    RT_RCCL(c, rc.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+    rc.comms = comms;
+    return RT_OK;
+}
+
+// The slots' shares -- d_share[s] on slot s's device, complete in the order of that slot's stream; d_share[0] is the first block
+// of slot 0's staging -- to slot 0, into image order, to host_out.  Blocking, like the entry points that call it.
+int frame_gather(rt_ctx* c, const FrameSplit& sp, uint32_t h, size_t row_bytes, void* const* d_share, char* shares, char* frame,
+                 void* host_out) {
+    const int ns = (int)sp.n_slots;
+    const size_t share_bytes = (size_t)sp.share_rows * row_bytes;
+    Replica& r0 = c->reps[0];
+    bool use_rccl = c->frame_exchange == 1;
+    if (c->frame_exchange == 0 && ns > 1 && distinct_devices(c)) {
+        use_rccl = rccl_prepare(c) == RT_OK;        // auto: RCCL when it is there, else peer copies (the reason stays in rccl.why)
+        c->err.clear();
+    }
+    const char* src = shares;                       // where launch_gather_rows reads the shares
+    if (use_rccl) {
+        int rcode = rccl_prepare(c);
+        if (rcode != RT_OK) return rcode;
+        Rccl& rc = c->rccl;
+        // Grouped point-to-point: slot s sends its share once, over its own xGMI link to slot 0; no ring, no reduction.
+        RT_RCCL(c, rc.GroupStart());
+        for (int s = 1; s < ns; ++s) {
+            RT_RCCL(c, rc.Send(d_share[s], share_bytes, ncclUint8, 0, rc.comms[s], c->reps[s].stream));
+            RT_RCCL(c, rc.Recv(shares + (size_t)s * share_bytes, share_bytes, ncclUint8, s, rc.comms[0], r0.stream));
+        }
+        if (ns == 1) {
+            // A context of ONE slot that asks for RCCL sends its share to itself, into the second block of the staging, and the
+            // frame is assembled from that copy: the whole plumbing -- dlopen, communicator, send / recv on the slot's stream,
+            // stream order against the kernels -- then runs on a one-GPU box too (tests/).
+            RT_RCCL(c, rc.Send(shares, share_bytes, ncclUint8, 0, rc.comms[0], r0.stream));
+            RT_RCCL(c, rc.Recv(shares + share_bytes, share_bytes, ncclUint8, 0, rc.comms[0], r0.stream));
+            src = shares + share_bytes;
+        }
+        RT_RCCL(c, rc.GroupEnd());
+        c->last_exchange = 1;
+    } else {
+        // peer copies on slot 0's stream, each behind the event that marks its source share complete
+        for (int s = 1; s < ns; ++s) {
+            Replica& r = c->reps[s];
+            RT_HIP(c, hipSetDevice(r.device));
+            RT_HIP(c, hipEventRecord(r.ev_share, r.stream));
+            RT_HIP(c, hipSetDevice(r0.device));
+            RT_HIP(c, hipStreamWaitEvent(r0.stream, r.ev_share, 0));
+            char* dst = shares + (size_t)s * share_bytes;
+            if (r.device == r0.device) RT_HIP(c, hipMemcpyAsync(dst, d_share[s], share_bytes, hipMemcpyDeviceToDevice, r0.stream));
+            else                       RT_HIP(c, hipMemcpyPeerAsync(dst, r0.device, d_share[s], r.device, share_bytes, r0.stream));
+        }
+        c->last_exchange = 2;
+    }
+    RT_HIP(c, hipSetDevice(r0.device));
+    RT_HIP(c, launch_gather_rows(reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(frame), h, (uint32_t)(row_bytes / 4),
+                                 kFrameStripe, sp.n_slots, sp.share_rows, r0.stream));
+    RT_HIP(c, hipMemcpyAsync(host_out, frame, (size_t)h * row_bytes, hipMemcpyDeviceToHost, r0.stream));
+    RT_HIP(c, hipStreamSynchronize(r0.stream));
+    for (int s = 1; s < ns; ++s) {                  // the senders' buffers are free again, and their errors surface here
+        RT_HIP(c, hipSetDevice(c->reps[s].device));
+        RT_HIP(c, hipStreamSynchronize(c->reps[s].stream));
+    }
+    return RT_OK;
+}
+
 void free_pipe(Replica& r) {
     HostPipe& p = r.pipe;
     p.pool.reset();
@@ -404,7 +576,8 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) try {
         bool ok = hipSetDevice(d) == hipSuccess && hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) == hipSuccess &&
                   hipMalloc(&r.d_counters, counter_words * sizeof(unsigned long long)) == hipSuccess &&
                   hipMemset(r.d_counters, 0, counter_words * sizeof(unsigned long long)) == hipSuccess &&
-                  noalloc_init(&r.d_noalloc) == hipSuccess;          // this device's address of the static scratch array
+                  noalloc_init(&r.d_noalloc) == hipSuccess &&        // this device's address of the static scratch array
+                  hipEventCreateWithFlags(&r.ev_share, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; ok && k < kNumScratchEvents; ++k) ok = hipEventCreateWithFlags(&r.sc_ev[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) { rt_destroy(c.release()); return RT_E_DEVICE; }
     }
@@ -416,9 +589,10 @@ int rt_create(rt_ctx** out, const int* device_ids, int n_devices) try {
 
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
+    for (Replica& r : c->reps) { (void)hipSetDevice(r.device); (void)hipDeviceSynchronize(); }   // *_dev launches may still be running on the caller's streams
+    c->rccl.destroy();
     for (Replica& r : c->reps) {
         (void)hipSetDevice(r.device);
-        (void)hipDeviceSynchronize();            // *_dev launches may still be running on the caller's streams
         free_scene(r);
         free_pipe(r);
         if (r.d_counters) (void)hipFree(r.d_counters);
@@ -427,6 +601,8 @@ void rt_destroy(rt_ctx* c) {
         if (r.d_spill) (void)hipFree(r.d_spill);
         if (r.d_prim) (void)hipFree(r.d_prim);
         if (r.d_render) (void)hipFree(r.d_render);
+        if (r.d_gather) (void)hipFree(r.d_gather);
+        if (r.ev_share) (void)hipEventDestroy(r.ev_share);
         for (hipEvent_t ev : r.sc_ev) if (ev) (void)hipEventDestroy(ev);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
@@ -456,6 +632,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) try {
         case RT_OPT_SAH_BINS:    if (v < 4 || v > 32) return fail(c, RT_E_INVALID, "RT_OPT_SAH_BINS in [4,32]"); c->sah_bins = (int)v; return RT_OK;
         case RT_OPT_SAH_TRAV:    if (v < 1 || v > 10000) return fail(c, RT_E_INVALID, "RT_OPT_SAH_TRAV in [1,10000] (hundredths)"); c->sah_trav_x100 = (int)v; return RT_OK;
         case RT_OPT_RAY_PACKETS: if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PACKETS: 0 off, 1 on"); c->ray_packets = (int)v; return RT_OK;
+        case RT_OPT_FRAME_EXCHANGE: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_FRAME_EXCHANGE: 0 auto, 1 RCCL, 2 peer copies"); c->frame_exchange = (int)v; return RT_OK;
         case RT_OPT_RAY_PAD:     if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PAD: 0 off, 1 on"); c->ray_pad = (int)v; return RT_OK;
         default: return fail(c, RT_E_INVALID, "unknown option key");
     }
@@ -771,6 +948,7 @@ int rt_shade_resolve_dev(rt_ctx* c, int slot, const rt_ray* d_rays, const rt_hit
 } RT_ABI_CATCH(c)
 
 // frag.glsl:303-360 for a whole frame, as a wavefront pipeline: k_primary, then per bounce k_shade + closest hit.
+// Several slots: each renders its interleaved share (FrameSplit), the shares are gathered on slot 0's device (frame_gather).
 int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces, uint32_t seed, uint8_t* host_rgba8) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();
@@ -779,40 +957,42 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
     if (!host_rgba8 || w == 0 || h == 0 || spp == 0 || bounces == 0) return fail(c, RT_E_INVALID, "render: null output or zero size");
     if ((uint64_t)w * h * spp > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "render: w*h*spp exceeds 2^32-1");
     const int ns = (int)c->reps.size();
-    const uint32_t per = ((h + ns - 1) / ns + 7) / 8 * 8;
     const int mode = c->mode();
-    return for_each_slot(c, [&](int s) -> int {
+    const bool gathered = ns > 1 || c->frame_exchange == 1;       // the frame is assembled on slot 0's device
+    if (gathered && h > 65535u) return fail(c, RT_E_TOO_LARGE, "render: more than 65535 rows with several slots");
+    const FrameSplit sp = frame_split(h, ns);
+    char* shares = nullptr; char* frame = nullptr;
+    if (gathered) { const int rc = frame_stage(c, sp, h, (size_t)w * 4, &shares, &frame); if (rc != RT_OK) return rc; }
+    std::vector<void*> d_share(ns, nullptr);
+    const int rc = for_each_slot(c, [&](int s) -> int {
         Replica& r = c->reps[s];
-        const uint32_t y0 = std::min<uint64_t>((uint64_t)per * s, h), y1 = std::min<uint64_t>((uint64_t)y0 + per, h);
-        if (y1 <= y0) return RT_OK;
-        const uint32_t rows = y1 - y0;
+        // one slot: the whole frame, rows in order.  Several: local row yl is image row y0 + (yl / 8) * 8 * ns + yl % 8.
+        const uint32_t y0 = gathered ? sp.y0(s) : 0, rows = gathered ? sp.share_rows : h;
+        const uint32_t stripe_h = gathered ? kFrameStripe : rows, step = gathered ? (uint32_t)ns : 1u;
+        const uint32_t row_len = gathered ? w * spp : 0u;        // RNG keys are path indices in the FULL frame either way
         const uint64_t n = (uint64_t)rows * w * spp, npx = (uint64_t)rows * w;
+        const bool in_place = gathered && s == 0;                // slot 0's RGBA8 share is the first block of the staging
         // rays A/B (32 B), hits (16 B), throughput (16 B), radiance (16 B) per ray + RGBA8 per pixel
-        const size_t bytes = n * (32 + 32 + 16 + 16 + 16) + npx * 4;
+        const size_t bytes = n * (32 + 32 + 16 + 16 + 16) + (in_place ? 0 : npx * 4);
         RT_HIP_SLOT(r, hipSetDevice(r.device));
-        if (bytes > r.render_cap) {
-            if (r.d_render) (void)hipFree(r.d_render);
-            r.d_render = nullptr; r.render_cap = 0;
-            RT_HIP_SLOT(r, hipMalloc(&r.d_render, bytes));
-            r.render_cap = bytes;
-        }
+        RT_HIP_SLOT(r, grow(&r.d_render, &r.render_cap, bytes));
         char* base = static_cast<char*>(r.d_render);
         rt_ray* ra = reinterpret_cast<rt_ray*>(base);
         rt_ray* rb = reinterpret_cast<rt_ray*>(base + n * 32);
         rt_hit* hits = reinterpret_cast<rt_hit*>(base + n * 64);
         float4* thr = reinterpret_cast<float4*>(base + n * 80);
         float4* rad = reinterpret_cast<float4*>(base + n * 96);
-        uint32_t* rgba = reinterpret_cast<uint32_t*>(base + n * 112);
+        uint32_t* rgba = in_place ? reinterpret_cast<uint32_t*>(shares) : reinterpret_cast<uint32_t*>(base + n * 112);
         const DevScene ds = c->dev_scene(r);
         // segment 0: primary rays + their shading in one kernel (the primary rays and hits stay in registers)
         const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
         if (primary_via_buffer(c)) {             // big tree: ray generation -> ray-buffer kernel -> first-segment shade
-            RT_HIP_SLOT(r, launch_primary(ds, c->cam, kNone, false, w, h, y0, rows, rows, 1, spp, seed, 1, rb, nullptr, r.d_counters, r.stream));
+            RT_HIP_SLOT(r, launch_primary(ds, c->cam, kNone, false, w, h, y0, rows, stripe_h, step, spp, seed, 1, rb, nullptr, r.d_counters, r.stream));
             RT_HIP_SLOT(r, trace_rays(c, r, false, false, rb, n, hits, nullptr, r.stream));
-            RT_HIP_SLOT(r, launch_shade(ds, mode, rb, hits, n, key0, 0, 1, 1, seed + 1u, thr, rad, bounces > 1 ? ra : nullptr, r.stream, true));
+            RT_HIP_SLOT(r, launch_shade(ds, mode, rb, hits, n, key0, row_len, stripe_h, step, seed + 1u, thr, rad, bounces > 1 ? ra : nullptr, r.stream, true));
         } else {
             const PrimaryShade ps = { thr, rad, bounces > 1 ? ra : nullptr, seed + 1u };
-            RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, rows, 1, spp, seed, 1, nullptr, nullptr, r.d_counters, r.stream, &ps));
+            RT_HIP_SLOT(r, launch_primary(ds, c->cam, mode, false, w, h, y0, rows, stripe_h, step, spp, seed, 1, nullptr, nullptr, r.d_counters, r.stream, &ps));
         }
         const bool fuse_last = bounces > 1 && spp <= 64 && (spp & (spp - 1)) == 0;    // last segment + resolve in one kernel
         for (uint32_t b = 1; b < bounces; ++b) {
@@ -821,14 +1001,19 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
                 RT_HIP_SLOT(r, launch_shade_resolve(ds, mode, ra, hits, n, spp, thr, rad, nullptr, rgba, r.stream));
                 break;
             }
-            RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, 0, 1, 1, seed + 1u + b, thr, rad, b + 1 < bounces ? rb : nullptr, r.stream));
+            RT_HIP_SLOT(r, launch_shade(ds, mode, ra, hits, n, key0, row_len, stripe_h, step, seed + 1u + b, thr, rad, b + 1 < bounces ? rb : nullptr, r.stream));
             std::swap(ra, rb);
         }
         if (!fuse_last) RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));
-        RT_HIP_SLOT(r, hipMemcpyAsync(host_rgba8 + (size_t)y0 * w * 4, rgba, npx * 4, hipMemcpyDeviceToHost, r.stream));
-        RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        d_share[s] = rgba;
+        if (!gathered) {
+            RT_HIP_SLOT(r, hipMemcpyAsync(host_rgba8, rgba, npx * 4, hipMemcpyDeviceToHost, r.stream));
+            RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        }
         return RT_OK;
     });
+    if (rc != RT_OK || !gathered) return rc;
+    return frame_gather(c, sp, h, (size_t)w * 4, d_share.data(), shares, frame, host_rgba8);
 } RT_ABI_CATCH(c)
 
 int rt_counters_get(rt_ctx* c, int slot, rt_counters* out, int reset) try {
@@ -865,28 +1050,46 @@ int rt_trace_primary(rt_ctx* c, uint32_t w, uint32_t h, rt_hit* host_out) try {
     if (!host_out || w == 0 || h == 0) return fail(c, RT_E_INVALID, "trace_primary: null output or empty image");
     if ((uint64_t)w * h > 0xFFFFFFFFull) return fail(c, RT_E_TOO_LARGE, "trace_primary: w*h exceeds 2^32-1");
     const int ns = (int)c->reps.size();
-    // contiguous row blocks, multiples of 8 rows so that 8x8 tiles stay whole
-    const uint32_t per = ((h + ns - 1) / ns + 7) / 8 * 8;
     const int mode = c->mode();
-    return for_each_slot(c, [&](int s) -> int {
+    const bool gathered = ns > 1 || c->frame_exchange == 1;       // interleaved 8-row stripes per slot, assembled on slot 0's device
+    if (gathered && h > 65535u) return fail(c, RT_E_TOO_LARGE, "trace_primary: more than 65535 rows with several slots");
+    const FrameSplit sp = frame_split(h, ns);
+    const size_t row_bytes = (size_t)w * sizeof(rt_hit);
+    char* shares = nullptr; char* frame = nullptr;
+    if (gathered) { const int rc = frame_stage(c, sp, h, row_bytes, &shares, &frame); if (rc != RT_OK) return rc; }
+    std::vector<void*> d_share(ns, nullptr);
+    const int rc = for_each_slot(c, [&](int s) -> int {
         Replica& r = c->reps[s];
-        const uint32_t y0 = std::min<uint64_t>((uint64_t)per * s, h), y1 = std::min<uint64_t>((uint64_t)y0 + per, h);
-        if (y1 <= y0) return RT_OK;
-        const uint32_t rows = y1 - y0;
-        const size_t bytes = (size_t)rows * w * sizeof(rt_hit);
+        const uint32_t y0 = gathered ? sp.y0(s) : 0, rows = gathered ? sp.share_rows : h;
+        const uint32_t stripe_h = gathered ? kFrameStripe : rows, step = gathered ? (uint32_t)ns : 1u;
+        const size_t bytes = (size_t)rows * row_bytes;
         RT_HIP_SLOT(r, hipSetDevice(r.device));
-        if (bytes > r.out_cap) {
-            if (r.d_out) (void)hipFree(r.d_out);
-            r.d_out = nullptr; r.out_cap = 0;
-            RT_HIP_SLOT(r, hipMalloc(&r.d_out, bytes));
-            r.out_cap = bytes;
+        rt_hit* out = reinterpret_cast<rt_hit*>(shares);          // slot 0 of a gathered frame writes its share in place
+        if (!(gathered && s == 0)) {
+            RT_HIP_SLOT(r, grow(&r.d_out, &r.out_cap, bytes));
+            out = static_cast<rt_hit*>(r.d_out);
         }
-        RT_HIP_SLOT(r, launch_primary(c->dev_scene(r), c->cam, mode, false, w, h, y0, rows, rows, 1, 1, 0, 0, nullptr,
-                                      static_cast<rt_hit*>(r.d_out), r.d_counters, r.stream));
-        RT_HIP_SLOT(r, hipMemcpyAsync(host_out + (size_t)y0 * w, r.d_out, bytes, hipMemcpyDeviceToHost, r.stream));
-        RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        if (primary_via_buffer(c)) {             // trees whose primary rays go through ray generation + the ray-buffer kernel
+            rt_ray* rays = nullptr;
+            rt_hit* hh = out;
+            const uint64_t n = (uint64_t)rows * w;
+            RT_HIP_SLOT(r, primary_scratch(r, n, &rays, &hh));
+            RT_HIP_SLOT(r, scratch_acquire(r, kEvPrim, r.stream));
+            RT_HIP_SLOT(r, launch_primary(c->dev_scene(r), c->cam, kNone, false, w, h, y0, rows, stripe_h, step, 1, 0, 0, rays, nullptr, r.d_counters, r.stream));
+            RT_HIP_SLOT(r, trace_rays(c, r, false, false, rays, n, out, nullptr, r.stream));
+            RT_HIP_SLOT(r, scratch_release(r, kEvPrim, r.stream));
+        } else {
+            RT_HIP_SLOT(r, launch_primary(c->dev_scene(r), c->cam, mode, false, w, h, y0, rows, stripe_h, step, 1, 0, 0, nullptr, out, r.d_counters, r.stream));
+        }
+        d_share[s] = out;
+        if (!gathered) {
+            RT_HIP_SLOT(r, hipMemcpyAsync(host_out, out, bytes, hipMemcpyDeviceToHost, r.stream));
+            RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+        }
         return RT_OK;
     });
+    if (rc != RT_OK || !gathered) return rc;
+    return frame_gather(c, sp, h, row_bytes, d_share.data(), shares, frame, host_out);
 } RT_ABI_CATCH(c)
 
 // Is p host memory the GPU can DMA from / to directly (rt_host_alloc, hipHostMalloc)?

@@ -485,6 +485,56 @@ def test_two_slots_on_one_device_equal_one_slot():
         assert a.trace_primary(61, 37).tobytes() == b.trace_primary(61, 37).tobytes()
 
 
+@pytest.mark.parametrize("w,h", [(61, 37), (96, 72), (40, 8), (33, 3)])
+def test_frames_of_several_slots_are_interleaved_shares_gathered_on_slot_0(w, h):
+    """rt_trace_primary / rt_render on a context of several slots: 8-row stripes dealt round-robin, gathered on slot 0's
+    device, one D2H.  Slots that repeat an ordinal take the peer-copy exchange; the frame must equal the
+    one-slot frame bit for bit (RNG keys are path indices in the full frame), and the oracle's."""
+    tris, sph, _ = scenes.cornell()
+    cam = rt.default_camera(w / h)
+    _, want = oracle.render(oracle.Scene(tris, sph, _lights2()), cam, w, h, 4, 3, 7)
+    ref_hits = oracle.trace_primary(oracle.Scene(tris, sph), cam, w, h)
+    frames = []
+    for devs in ((0,), (0, 0), (0, 0, 0), (0,) * 5):
+        with rt.Renderer(devs) as r:
+            r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+            r.create_data(tris, sph, _lights2())
+            r.update_camera(cam)
+            hits = r.trace_primary(w, h)
+            assert hits.tobytes() == ref_hits.tobytes(), devs
+            frames.append(r.render(w, h, spp=4, bounces=3, seed=7))
+            frames.append(r.render(w, h, spp=3, bounces=2, seed=7))            # spp not a power of two: separate resolve
+    for k in range(2, len(frames)):
+        assert np.array_equal(frames[k], frames[k % 2]), f"slots variant {k // 2} differs from one slot"
+    assert np.abs(frames[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_rccl_frame_exchange_inside_the_library():
+    """RT_OPT_FRAME_EXCHANGE = 1: the gather goes through RCCL (librccl.so.1 loaded by the library, ncclCommInitAll, grouped
+    ncclSend / ncclRecv on the slots' streams).  One GPU here, so the communicator has ONE rank and the slot sends its
+    share to itself before the frame is assembled from the received copy; N > 1 ranks in one process are unexecuted.
+    Repeated ordinals cannot form a communicator: a clear error, and auto (0) falls back to peer copies."""
+    tris, sph, _ = scenes.cornell()
+    w, h = 96, 52
+    cam = rt.default_camera(w / h)
+    with rt.Renderer((0,)) as a, rt.Renderer((0,)) as b, rt.Renderer((0, 0)) as two:
+        for r in (a, b, two):
+            r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+            r.create_data(tris, sph, _lights2())
+            r.update_camera(cam)
+        b.set_option(rt.OPT_FRAME_EXCHANGE, 1)
+        for _ in range(2):                                                    # second call: communicator and staging reused
+            assert np.array_equal(a.render(w, h, spp=4, bounces=3, seed=5), b.render(w, h, spp=4, bounces=3, seed=5))
+            assert a.trace_primary(w, h).tobytes() == b.trace_primary(w, h).tobytes()
+        two.set_option(rt.OPT_FRAME_EXCHANGE, 1)
+        with pytest.raises(RuntimeError, match="distinct device ordinals"):
+            two.render(w, h, spp=4, bounces=3, seed=5)
+        two.set_option(rt.OPT_FRAME_EXCHANGE, 0)
+        assert np.array_equal(two.render(w, h, spp=4, bounces=3, seed=5), a.render(w, h, spp=4, bounces=3, seed=5))
+        with pytest.raises(RuntimeError):
+            two.set_option(rt.OPT_FRAME_EXCHANGE, 3)
+
+
 # ---- C2 / C3 stand-ins: sampled against the oracle, full frames against the GPU brute-force loop --------------
 def test_c2_bunny_class_primary_and_shadow_sample(renderer, torch_dev):
     torch = torch_dev
