@@ -5,7 +5,10 @@
 // (consequence 2); DESIGN.md explains how boxes are padded so that traversal
 // never culls the primitive the loop would have chosen.
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace rt {
@@ -22,10 +25,30 @@ struct Aabb {
 };
 
 // Binary build tree.  count > 0 => leaf over prim_index[first, first+count).
-struct BuildNode {
+struct BuildNode {            // trivially constructible on purpose: see NodeArray
     Aabb box;
-    uint32_t left = 0, right = 0;
-    uint32_t first = 0, count = 0;
+    uint32_t left, right;
+    uint32_t first, count;
+};
+
+// The build nodes of a tree: up to 2n - 1 records for n primitives, of which a build with 4-triangle leaves uses a third.
+// Storage is allocated UNINITIALISED (a std::vector would write all 800 MB of a 10 M-triangle build's worst case before the
+// first node exists); the builder fills every node it hands out, size() is the number handed out.
+class NodeArray {
+public:
+    void allocate(size_t capacity) { p_.reset(capacity ? new BuildNode[capacity] : nullptr); cap_ = capacity; n_ = capacity; }
+    void resize_down(size_t n) { if (n < n_) n_ = n; }
+    void clear() { p_.reset(); cap_ = n_ = 0; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    BuildNode& operator[](size_t i) { return p_[i]; }
+    const BuildNode& operator[](size_t i) const { return p_[i]; }
+    const BuildNode* begin() const { return p_.get(); }
+    const BuildNode* end() const { return p_.get() + n_; }
+    void swap(NodeArray& o) { p_.swap(o.p_); std::swap(cap_, o.cap_); std::swap(n_, o.n_); }
+private:
+    std::unique_ptr<BuildNode[]> p_;
+    size_t cap_ = 0, n_ = 0;
 };
 
 struct BuildParams {
@@ -38,11 +61,12 @@ struct BuildParams {
 };
 
 struct BuildResult {
-    std::vector<BuildNode> nodes;      // nodes[0] = root
+    NodeArray nodes;                   // nodes[0] = root
     std::vector<uint32_t>  prim_index; // permutation of [0, n)
     uint32_t depth = 0;
     uint32_t n_leaves = 0;
     float    sah_cost = 0.f;
+    bool     oversize_leaf = false;   // some leaf holds more than 8 primitives (the depth budget ran out): not flattenable
 };
 
 // prim_boxes: n exact (unpadded) primitive bounds.
@@ -86,7 +110,7 @@ struct FlatBvh4q {
     std::vector<uint32_t> wide;       // filled only when flatten_bvh4q is asked to (want_wide)
 };
 
-void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out, bool want_wide = false);
+void flatten_bvh4q(const BuildResult& b, float pad, FlatBvh4q& out, bool want_wide = false, int threads = 0);
 
 // exact bound on the BVH2 traversal stack (entries pushed along the worst root-to-leaf path)
 uint32_t bvh2_stack_need(const BuildResult& b);
