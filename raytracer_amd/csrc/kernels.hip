@@ -720,6 +720,21 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];             // plain ds_read; deep lanes fix it up below
             if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
         }
+#ifdef RT_SWAP_BLOCKED
+        // EXPERIMENT (profiles/r04i_swap_blocked.txt): a lane that holds a parked leaf and stands on a second one cannot walk on
+        // until the triangle block has emptied the parked one.  Here it puts the second leaf back under the top of its stack
+        // and walks on with the interior node that was there (any order is correct: consider() is order-independent).
+        {
+            const bool blocked = pend != 0 && node < 0 && node != kDone && sp > 1;
+            const int ti = sp - 1;
+            int top = stk[(CAPPED ? min(ti, lds_cap - 1) : ti) * kBlock];
+            if (CAPPED && ti >= lds_cap) top = *spill_slot(spill, ti);
+            if (blocked && top >= 0) {
+                if (!CAPPED || ti < lds_cap) stk[ti * kBlock] = node; else *spill_slot(spill, ti) = node;
+                node = top;
+            }
+        }
+#endif
         // A second interior step in the same round when most of the wave still stands on interior nodes: the round's fixed
         // work (refill vote, leaf parking, triangle-block vote, result write: ~65 VALU instructions against 114 for the node
         // step) is then spread over two steps.  Below the threshold the step would run half empty and cost more than it saves
@@ -1314,24 +1329,47 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const rt_ray* __restrict__
     for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) row[b] = h[b];
 }
 
-// hist[block][bin] -> exclusive prefix over blocks (in place); totals[bin] = rays of the bin
+// hist[block][bin] -> exclusive prefix over blocks (in place); totals[bin] = rays of the bin.
+// A workgroup takes 16 bins x 16 segments of the rows: a thread sums its segment, the segment sums are scanned through LDS,
+// then the thread walks its segment again and writes the running prefix.  (One thread per bin over all rows took 57 us for
+// 1,024 rows whatever the buffer's size -- a tenth of a 4 Mi-ray call's binning; profiles/r04e_c4_kernels_by_ray_count.txt.)
+constexpr uint32_t kColBins = 16, kColSegs = kBlock / kColBins;
 __global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t bins, uint32_t* __restrict__ totals,
                                                         uint32_t* __restrict__ meta /* [1] += non-empty (block, bin) pairs; null = do not count */) {
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= bins) return;
-    uint32_t run = 0, pairs = 0;
-    for (uint32_t k0 = 0; k0 < n_blocks; k0 += 16) {         // 16 independent loads in flight, then the serial prefix
+    __shared__ uint32_t part[kColSegs][kColBins];
+    const uint32_t bl = threadIdx.x % kColBins, seg = threadIdx.x / kColBins;
+    const uint32_t b = blockIdx.x * kColBins + bl;
+    const uint32_t per = (n_blocks + kColSegs - 1) / kColSegs;
+    const uint32_t r0 = min(seg * per, n_blocks), r1 = min(r0 + per, n_blocks);
+    const bool in = b < bins;
+    uint32_t sum = 0;
+    if (in) {
+        for (uint32_t k0 = r0; k0 < r1; k0 += 16) {             // 16 independent loads in flight
+            uint32_t v[16];
+            #pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) v[j] = (k0 + j < r1) ? hist[(size_t)(k0 + j) * bins + b] : 0u;
+            #pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) sum += v[j];
+        }
+    }
+    part[seg][bl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (uint32_t sgm = 0; sgm < kColSegs; ++sgm) { const uint32_t v = part[sgm][bl]; run += sgm < seg ? v : 0u; total += v; }
+    if (!in) return;
+    uint32_t pairs = 0;
+    for (uint32_t k0 = r0; k0 < r1; k0 += 16) {
         uint32_t v[16];
         #pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) v[j] = (k0 + j < n_blocks) ? hist[(size_t)(k0 + j) * bins + b] : 0u;
+        for (uint32_t j = 0; j < 16; ++j) v[j] = (k0 + j < r1) ? hist[(size_t)(k0 + j) * bins + b] : 0u;
         #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
-            if (k0 + j < n_blocks) hist[(size_t)(k0 + j) * bins + b] = run;
+            if (k0 + j < r1) hist[(size_t)(k0 + j) * bins + b] = run;
             run += v[j];
             pairs += v[j] != 0u;
         }
     }
-    totals[b] = run;
+    if (seg == 0) totals[b] = total;
     if (meta && pairs) atomicAdd(&meta[1], pairs);
 }
 
@@ -1524,7 +1562,7 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
     if (e != hipSuccess) return e;
     if (!two_level) {
         hipLaunchKernelGGL(k_bin_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist);
-        hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, meta);
+        hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, meta);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 1);
         hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, meta, perm);
         return hipGetLastError();
@@ -1539,11 +1577,11 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
     uint32_t* hist_hi = hist;                                                // rows of kBinsHi words; the full-width rows reuse the area afterwards
     uint32_t* totals_hi = totals;
     hipLaunchKernelGGL(k_bin2_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, keys, hist_hi, meta);
-    hipLaunchKernelGGL(k_bin_columns, dim3(1), dim3(kBlock), 0, st, hist_hi, n_blocks, kBinsHi, totals_hi, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBinsHi + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist_hi, n_blocks, kBinsHi, totals_hi, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals_hi, kBinsHi, meta, n, min_run, 1);
     hipLaunchKernelGGL(k_bin2_scatter_hi, dim3(n_blocks), dim3(kBlock), 0, st, keys, n, per_block, hist_hi, totals_hi, meta, tmp_idx, tmp_key);
     hipLaunchKernelGGL(k_bin2_count_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, n, per_block, meta, hist);
-    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kBlock - 1) / kBlock), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 0);
     hipLaunchKernelGGL(k_bin2_scatter_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, tmp_idx, n, per_block, hist, totals, meta, perm);
     return hipGetLastError();
