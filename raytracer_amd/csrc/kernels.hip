@@ -625,10 +625,14 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
     if (perm && perm_on && *perm_on == 0u) perm = nullptr;             // launch_bin found the buffer coherent already
-    uint64_t cursor = 0, end = 0;                                     // wave-uniform: the chunk being handed out
+    // Wave-uniform state of the chunk being handed out, all 32 bits wide so that it lives in SGPRs and the per-round tests are
+    // scalar compares (a 64-bit cursor / end pair needs v_cmp_lt_u64: the compiler then keeps the whole chain -- cursor, end,
+    // the eighth's number, the mask of exhausted eighths -- in six VGPRs of the 72 this kernel has): chunk number, rays of
+    // the chunk handed out so far, rays in the chunk.  launch_trace keeps n below 2^32 chunks.
+    uint32_t chunk = 0, cur = 0, lim = 0;
     bool more = true;                                                 // wave-uniform: some cursor is not exhausted
-    const uint64_t n_chunks = (n + strip - 1) / strip;
-    const uint32_t per_q = (uint32_t)((n_chunks + 7) / 8);            // chunks per eighth
+    const uint32_t n_chunks = (uint32_t)((n + strip - 1) / strip);
+    const uint32_t per_q = (n_chunks + 7u) / 8u;                      // chunks per eighth
     uint32_t q = blockIdx.x & 7u, q_done = 0;                         // workgroups go round-robin over the 8 XCDs
     const Spill spill = { CAPPED ? spill_base : nullptr, gridDim.x * (uint32_t)kBlock, lds_cap };
     stk[0] = kDone;
@@ -643,23 +647,28 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
     uint32_t w_rounds = 0, w_i = 0, w_t = 0;    // wave-uniform scheduling probes (COUNT builds)
     uint32_t w_idle = 0, w_blocked = 0, w_pend = 0, w_tblocks = 0;
     int pend = 0;                               // postponed leaf (leaf refs are negative; 0 = none)
+#ifdef RT_PEND2
+    int pend2 = 0;                              // -DRT_PEND2, measured and not the default (profiles/r04m_pend2.txt): a second postponed leaf,
+                                                // only ever set while pend is.  Bench frame -1.4 %, 10 M-triangle soup +3.3 %.
+#endif
     for (;;) {
         const bool idle = node == kDone && pend == 0;
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
-        if (cursor >= end && more && n_idle >= refill) {
+        if (cur >= lim && more && n_idle >= refill) {
             // draw the next chunk: own eighth of the buffer first (one cursor per XCD, so that an XCD's L2 sees one
             // contiguous -- with binning: spatially compact -- part of the rays), then the other eighths
-            cursor = end = 0;
+            cur = lim = 0;
             while (more) {
-                const uint64_t first = (uint64_t)q * per_q;
-                const uint32_t left = first >= n_chunks ? 0u : (per_q < n_chunks - first ? per_q : (uint32_t)(n_chunks - first));
+                const uint32_t first = q * per_q;
+                const uint32_t left = first >= n_chunks ? 0u : (per_q < n_chunks - first ? per_q : n_chunks - first);
                 unsigned long long c0 = ~0ull;
                 if (left && (threadIdx.x & 63) == 0) c0 = atomicAdd(&work[q * kCursorStride], 1ull);
                 const uint32_t got = __builtin_amdgcn_readfirstlane((uint32_t)c0);
                 if (got < left) {
-                    cursor = (first + got) * strip;
-                    end = (cursor + strip < n) ? cursor + strip : n;
+                    chunk = first + got;
+                    const uint64_t rest = n - (uint64_t)chunk * strip;
+                    lim = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(rest < strip ? rest : strip));
                     break;
                 }
                 // This eighth is exhausted.  Thousands of waves get here at the end of a launch; failed draws on the
@@ -677,10 +686,10 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                 q = (q + (uint32_t)__builtin_ctz(rot)) & 7u;
             }
         }
-        if (cursor < end && n_idle >= refill) {
+        if (cur < lim && n_idle >= refill) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-            const uint64_t cand = cursor + rank;
-            if (idle && cand < end) {
+            if (idle && cur + rank < lim) {
+                const uint64_t cand = (uint64_t)chunk * strip + cur + rank;
                 my = perm ? (uint64_t)perm[cand] : cand;
                 const float4* rp = reinterpret_cast<const float4*>(rays + my);
                 float4 r0 = rp[0], r1 = rp[1];
@@ -701,11 +710,11 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                     else     hits[my] = pack_hit(b, tmax);
                 }
             }
-            cursor += (uint64_t)n_idle;
+            cur += (uint32_t)n_idle;
         }
         const bool live = !(node == kDone && pend == 0);
         if (__ballot(live) == 0ull) {
-            if (cursor >= end && !more) break;
+            if (cur >= lim && !more) break;
             continue;
         }
         // if-if scheduling with one postponed leaf per lane: per round every lane does at most ONE interior
@@ -715,24 +724,18 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         const bool need_i = node >= 0;
         if (COUNT) { ++w_rounds; w_i += __popcll(__ballot(need_i)); w_idle += __popcll(__ballot(node == kDone && pend == 0)); }
         if (need_i) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
+#ifdef RT_PEND2
+        if (node < 0 && node != kDone && pend2 == 0) {
+            if (pend == 0) pend = node; else pend2 = node;
+            --sp;
+            node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];
+            if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
+        }
+#else
         if (node < 0 && node != kDone && pend == 0) {
             pend = node; --sp;
             node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];             // plain ds_read; deep lanes fix it up below
             if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
-        }
-#ifdef RT_SWAP_BLOCKED
-        // EXPERIMENT (profiles/r04i_swap_blocked.txt): a lane that holds a parked leaf and stands on a second one cannot walk on
-        // until the triangle block has emptied the parked one.  Here it puts the second leaf back under the top of its stack
-        // and walks on with the interior node that was there (any order is correct: consider() is order-independent).
-        {
-            const bool blocked = pend != 0 && node < 0 && node != kDone && sp > 1;
-            const int ti = sp - 1;
-            int top = stk[(CAPPED ? min(ti, lds_cap - 1) : ti) * kBlock];
-            if (CAPPED && ti >= lds_cap) top = *spill_slot(spill, ti);
-            if (blocked && top >= 0) {
-                if (!CAPPED || ti < lds_cap) stk[ti * kBlock] = node; else *spill_slot(spill, ti) = node;
-                node = top;
-            }
         }
 #endif
         // A second interior step in the same round when most of the wave still stands on interior nodes: the round's fixed
@@ -742,11 +745,20 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         if ((int)__popcll(__ballot(node >= 0)) >= kSecondStepLanes) {
             if (COUNT) { w_i += __popcll(__ballot(node >= 0)); }
             if (node >= 0) node = bvh_step<MODE, COUNT, CAPPED>(nodes, node, sl, tmin0, b.t, stk, sp, c, spill);
+#ifdef RT_PEND2
+            if (node < 0 && node != kDone && pend2 == 0) {
+                if (pend == 0) pend = node; else pend2 = node;
+                --sp;
+                node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];
+                if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
+            }
+#else
             if (node < 0 && node != kDone && pend == 0) {
                 pend = node; --sp;
                 node = stk[(CAPPED ? min(sp, lds_cap - 1) : sp) * kBlock];
                 if (CAPPED && sp >= lds_cap) node = *spill_slot(spill, sp);
             }
+#endif
         }
         const bool need_t = pend != 0;
         const unsigned long long mt = __ballot(need_t);
@@ -761,8 +773,14 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                 if (tri_hit(o, d, mk(q0.x, q0.y, q0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), t, u, v))
                     consider(b, tmin, t, u, v, __float_as_uint(q0.w) | kKeyFlip);
                 if (COUNT) ++c.tris;
+#ifdef RT_PEND2
+                if (ANY && b.t < tmax) { node = kDone; pend = 0; pend2 = 0; sp = 1; }
+                else if (ref & 7u) pend = (int)~(ref + 7u);
+                else { pend = pend2; pend2 = 0; }
+#else
                 if (ANY && b.t < tmax) { node = kDone; pend = 0; sp = 1; }
                 else pend = (ref & 7u) ? (int)~(ref + 7u) : 0;       // next triangle of the leaf: first+1, remaining-1
+#endif
             }
         }
         if (live && node == kDone && pend == 0) {
@@ -1626,6 +1644,7 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         const size_t lds = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
         const uint64_t n_chunks = (n + strip - 1) / strip;
+        if (n_chunks + 8 > 0xFFFFFFFFull) return hipErrorInvalidValue;      // the kernel counts chunks in 32 bits (2^38 rays at the smallest chunk)
         // a full grid when there are chunks for it (>= 8 per wave by the chunk size above, down to 1 for small buffers,
         // where putting every ray in flight at once matters more than the tail); sc.max_blocks bounds the spill columns
         uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));

@@ -317,6 +317,12 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         set = (int)(r.scratch_seq++ % kSpillSlots);
         sc.work = r.d_counters + kCountersPad + (size_t)set * kWorkWords;
         sc.lds_cap = c->lds_stack;
+        // Structures that do not fit the L2s (the ones whose rays get binned), buffers below 2^25 rays: the rays in flight at
+        // once are a large part of the buffer, so the region of the scene they touch outgrows the caches (10 M-triangle soup,
+        // 8 Mi rays: L2 hit 52 %, HBM 5.8 TB/s -- the launch is HBM-bound; profiles/r04j_c4_8mi_summary.md).  Fewer resident
+        // waves (32 stack entries in LDS: 5 blocks per CU instead of 7) shrink that region: 2 Mi rays +12 %, 4-16 Mi +3-5 %,
+        // from 32 Mi on the smaller cap is ahead again (profiles/r04k_c4_cap_sweep.txt).
+        if (bin && sc.lds_cap >= 2 && n < (1ull << 25)) sc.lds_cap = std::max(sc.lds_cap, 32);
         if (mode == kBvh4q) {
             const uint64_t words = c->lds_stack ? spill_words(c->stack_need, c->lds_stack, device_cus()) : 0;
             if (words) {
