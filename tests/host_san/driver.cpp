@@ -89,6 +89,24 @@ int main(int argc, char** argv) {
         EXPECT(rt_gen_soup(0x5EED0001ull, n, 0.02f, t.data(), n) == n);
         for (int leaf : { 1, 4, 8 }) for (int th : { 1, 5 }) build_and_flatten(t, leaf, th);
     }
+    // above 2^19 primitives the top of the tree is split data-parallel (bvh.cpp, phase 1): same tree for 1 and 4 threads
+    {
+        const uint32_t n = 600000;
+        std::vector<Triangle> t(n);
+        EXPECT(rt_gen_soup(0x5EED0001ull, n, 0.004f, t.data(), n) == n);
+        build_and_flatten(t, 4, 4);
+        rt_scene_stats s1, s4;
+        std::vector<uint32_t> n1((size_t)n * 16), n4((size_t)n * 16), o1(n), o4(n);
+        EXPECT(rt_bvh_build_host(t.data(), n, sizeof(Triangle), 3, 4, 15, 1, &s1, n1.data(), n1.size(), o1.data()) == RT_OK);
+        EXPECT(rt_bvh_build_host(t.data(), n, sizeof(Triangle), 3, 4, 15, 4, &s4, n4.data(), n4.size(), o4.data()) == RT_OK);
+        EXPECT(s1.n_nodes == s4.n_nodes && n1 == n4 && o1 == o4);
+        for (long k : { 2L, 7L, 13L, 21L, 34L }) {      // allocation failures while the fork-join passes run
+            g_countdown.store(k);
+            const int rc = rt_bvh_build_host(t.data(), n, sizeof(Triangle), 3, 4, 15, 4, &s4, n4.data(), n4.size(), o4.data());
+            g_countdown.store(-1);
+            EXPECT(rc == RT_OK || rc == RT_E_NOMEM);
+        }
+    }
     // degenerate: all triangles identical (forces median splits down to the depth budget), zero-area, huge coordinates
     {
         std::vector<Triangle> t(5000);

@@ -509,6 +509,26 @@ def test_frames_of_several_slots_are_interleaved_shares_gathered_on_slot_0(w, h)
     assert np.abs(frames[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
+@pytest.mark.parametrize("primary", [1, 2, 3])
+def test_host_frames_on_every_primary_path_and_slot_count(primary):
+    """rt_trace_primary / rt_render with RT_OPT_PRIMARY = 1 (tile kernel), 2 (ray generation + ray-buffer kernel, also behind
+    the host entry points since round 3) and 3 (packet walk), on one slot and on three: the oracle's hit buffer, one frame."""
+    tris, sph, _ = scenes.cornell32()[0], None, None
+    w, h = 75, 43
+    cam = rt.default_camera(w / h)
+    ref = oracle.trace_primary(oracle.Scene(tris, None), cam, w, h)
+    frames = []
+    for devs in ((0,), (0, 0, 0)):
+        with rt.Renderer(devs) as r:
+            r.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH)
+            r.set_option(rt.OPT_PRIMARY, primary)
+            r.create_data(tris, None, _lights2())
+            r.update_camera(cam)
+            assert r.trace_primary(w, h).tobytes() == ref.tobytes(), (primary, devs)
+            frames.append(r.render(w, h, spp=2, bounces=3, seed=11))
+    assert np.array_equal(frames[0], frames[1])
+
+
 def test_rccl_frame_exchange_inside_the_library():
     """RT_OPT_FRAME_EXCHANGE = 1: the gather goes through RCCL (librccl.so.1 loaded by the library, ncclCommInitAll, grouped
     ncclSend / ncclRecv on the slots' streams).  One GPU here, so the communicator has ONE rank and the slot sends its

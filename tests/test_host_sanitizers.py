@@ -27,3 +27,18 @@ def test_host_sources_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe), str(scratch)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "0 failures" in r.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_build_under_thread_sanitizer(tmp_path):
+    """The parallel host build (fork-join passes of the big nodes, subtree task pool, parallel flatten and record loops) under
+    ThreadSanitizer: 700 k triangles take the data-parallel phase, 90 k the task pool alone."""
+    exe = tmp_path / "host_tsan"
+    srcs = [os.path.join(ROOT, "tests", "host_san", "tsan_driver.cpp")] + [os.path.join(CSRC, f) for f in ("scene_host.cpp", "bvh.cpp", "scene_gen.cpp")]
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", *srcs, "-o", str(exe), "-lpthread"],
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout[-1000:], r.stderr[-4000:])
