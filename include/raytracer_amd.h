@@ -84,6 +84,9 @@ enum {
                                the buffer walk the tree together as one packet, like the primary rays of the tile kernel.  Same hit records for any
                                buffer; faster only when consecutive rays really travel together (same region, similar
                                direction), slower -- possibly much -- when they do not.  Default 0. */
+    RT_OPT_FUSED_PATHS = 18, /* rt_render on scenes traced by the brute-force loop (<= 32 triangles, e.g. the reference's Cornell box):
+                               1 (default) = the whole path loop of a sample in one kernel, ray / throughput / radiance in registers;
+                               0 = the staged pipeline (trace and shade kernels per segment).  Same frame, bit for bit. */
     RT_OPT_FRAME_EXCHANGE = 16, /* contexts with several slots, rt_render / rt_trace_primary: how the slots' interleaved 8-row stripes
                                reach slot 0's device, where they are put in image order and leave in ONE device-to-host copy.
                                1 = RCCL: grouped ncclSend / ncclRecv, every slot over its own xGMI link to slot 0 (librccl.so.1 is

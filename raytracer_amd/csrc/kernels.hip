@@ -969,6 +969,24 @@ __device__ __forceinline__ bool shade_one(const DevScene& s, float4 r0, float4 r
 // With SHADE the first segment of the path loop (:310-354, throughput 1, radiance 0) runs in the same kernel:
 // the primary ray and its hit never travel through HBM (rays_out / hits become optional outputs), and the
 // path-state buffers are written once instead of filled, read and written.
+// frag.glsl:89-128 for pixel (x, y) of a w x h image; key = index of the path in the full frame (RNG)
+__device__ __forceinline__ void camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t key, uint32_t seed,
+                                           int jitter, f3& o, f3& d) {
+    float uvx = ((float)x + 0.5f) / (float)w;                     // vert.glsl:9-12 pixel centre
+    float uvy = ((float)y + 0.5f) / (float)h;
+    float ndcx = __fmaf_rn(uvx, 2.0f, -1.0f), ndcy = __fmaf_rn(uvy, 2.0f, -1.0f);   // :91
+    if (jitter) {                                                 // :94-103
+        ndcx += (rand01(key, 0u, seed) - 0.5f) * (2.0f / 1920.0f);
+        ndcy += (rand01(key, 1u, seed) - 0.5f) * (2.0f / 1080.0f);
+    }
+    float a = ndcx * cam.half_w, bb = ndcy * cam.half_h;          // :114-115
+    d = mk(__fmaf_rn(bb, cam.ux, a * cam.rx) + cam.fx, __fmaf_rn(bb, cam.uy, a * cam.ry) + cam.fy,
+           __fmaf_rn(bb, cam.uz, a * cam.rz) + cam.fz);
+    d = norm3(d);                                                 // :113
+    d = norm3(d);                                                 // :120
+    o = mk(cam.px, cam.py, cam.pz);
+}
+
 struct ShadeOut { float4* thr; float4* rad; float4* next; uint32_t seed; };
 template <int MODE, bool COUNT, bool SHADE, bool PACKET>
 __device__ __forceinline__ void primary_body(int* stack /* dynamic LDS */, const DevScene& s, const DevCamera& cam, uint32_t w, uint32_t h, uint32_t y0,
@@ -992,21 +1010,7 @@ __device__ __forceinline__ void primary_body(int* stack /* dynamic LDS */, const
     const float tmin = 0.0f, tmax = 1e20f;                            // :266
     const uint32_t key = (y * w + x) * spp + smp;                     // RNG key: full-image ray index
     Best b;
-    if (active) {
-        float uvx = ((float)x + 0.5f) / (float)w;                     // vert.glsl:9-12 pixel centre
-        float uvy = ((float)y + 0.5f) / (float)h;
-        float ndcx = __fmaf_rn(uvx, 2.0f, -1.0f), ndcy = __fmaf_rn(uvy, 2.0f, -1.0f);   // :91
-        if (jitter) {                                                 // :94-103
-            ndcx += (rand01(key, 0u, seed) - 0.5f) * (2.0f / 1920.0f);
-            ndcy += (rand01(key, 1u, seed) - 0.5f) * (2.0f / 1080.0f);
-        }
-        float a = ndcx * cam.half_w, bb = ndcy * cam.half_h;          // :114-115
-        d = mk(__fmaf_rn(bb, cam.ux, a * cam.rx) + cam.fx, __fmaf_rn(bb, cam.uy, a * cam.ry) + cam.fy,
-               __fmaf_rn(bb, cam.uz, a * cam.rz) + cam.fz);
-        d = norm3(d);                                                 // :113
-        d = norm3(d);                                                 // :120
-        o = mk(cam.px, cam.py, cam.pz);
-    }
+    if (active) camera_ray(cam, x, y, w, h, key, seed, jitter, o, d);
     int* stk = stack + (MODE == kBvh2 || MODE == kBvh4q ? threadIdx.x : 0);
     if (PACKET) {
         // the whole wave walks the tree together (trace_packet); lanes without a ray only follow
@@ -1077,6 +1081,35 @@ void k_primary_packet(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_
                       uint32_t spp, uint32_t seed, int jitter, uint32_t tiles_x, uint32_t n_waves, float4* __restrict__ rays_out,
                       float4* __restrict__ hits, unsigned long long* counters, ShadeOut so, int quad) {
     primary_body<kBvh4q, COUNT, SHADE, true>(nullptr, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, seed, jitter, tiles_x, n_waves, rays_out, hits, counters, so, quad);
+}
+
+// The whole path loop of one sample (frag.glsl:306-354) in ONE kernel, for scenes that are traced by the reference's own
+// brute-force loop (up to 32 triangles: the reference's Cornell box is 12 + 3 spheres).  Such a frame is bound by the memory
+// traffic of the staged pipeline (192 bytes per path segment between the trace and shade kernels), not by its arithmetic, and
+// with no traversal there is no divergence to manage: a thread keeps ray, throughput and radiance in registers over all bounces
+// and writes 16 bytes at the end.  Same functions in the same order as the stages, hence the same radiance bit for bit.
+__global__ __launch_bounds__(kBlock) void k_path_brute(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+                                                       uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t bounces,
+                                                       uint32_t seed, float4* __restrict__ rad) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint64_t)rows * w * spp) return;
+    const uint32_t smp = (uint32_t)(i % spp), px = (uint32_t)(i / spp), x = px % w, yl = px / w;
+    const uint32_t y = y0 + (yl / stripe_h) * stripe_h * stripe_step + (yl % stripe_h);
+    f3 C = mk(0.0f, 0.0f, 0.0f);
+    if (y < h) {                                                      // rows beyond the image: padding of an interleaved share
+        const uint32_t key = (y * w + x) * spp + smp;
+        f3 o, d, T = mk(1.0f, 1.0f, 1.0f);
+        camera_ray(cam, x, y, w, h, key, seed, 1, o, d);
+        for (uint32_t b = 0; b < bounces; ++b) {
+            Best bst; Counters c = { 0, 0, 0, 0 };
+            trace_ray<kBrute, false, false>(s, o, d, 0.0f, 1e20f, bst, c, nullptr);
+            const float4 r0 = make_float4(o.x, o.y, o.z, 0.0f), r1 = make_float4(d.x, d.y, d.z, 1e20f), hit = pack_hit(bst, 1e20f);
+            f3 no, nd;
+            if (!shade_one<kBrute>(s, r0, r1, hit, T, C, key, seed + 1u + b, b + 1 < bounces, nullptr, no, nd)) break;   // :351-353
+            o = no; d = nd;
+        }
+    }
+    rad[i] = make_float4(C.x, C.y, C.z, 0.0f);
 }
 
 // frag.glsl:321-330 for one light, fused: shadow-ray build + closest-hit + lit test.
@@ -1809,6 +1842,16 @@ hipError_t launch_resolve(const float4* d_radiance, uint64_t n_pixels, uint32_t 
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, d, n, make_float4(x, y, z, w));
+    return hipGetLastError();
+}
+
+hipError_t launch_path_brute(const DevScene& s, const DevCamera& cam, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows, uint32_t stripe_h,
+                             uint32_t stripe_step, uint32_t spp, uint32_t bounces, uint32_t seed, float4* d_radiance, hipStream_t st) {
+    if (rows == 0 || w == 0 || spp == 0) return hipSuccess;
+    if (stripe_h == 0 || stripe_step == 0 || bounces == 0 || !d_radiance) return hipErrorInvalidValue;
+    const uint64_t n = (uint64_t)rows * w * spp;
+    if (n > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_path_brute, dim3(grid_for(n)), dim3(kBlock), 0, st, s, cam, w, h, y0, rows, stripe_h, stripe_step, spp, bounces, seed, d_radiance);
     return hipGetLastError();
 }
 

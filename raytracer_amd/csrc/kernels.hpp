@@ -118,6 +118,10 @@ hipError_t launch_shade_resolve(const DevScene& s, int mode, const rt_ray* d_ray
                                 uint32_t spp, const float4* d_throughput, const float4* d_radiance, float4* d_linear,
                                 uint32_t* d_rgba8, hipStream_t st);
 hipError_t launch_fill(float4* d, uint64_t n, float x, float y, float z, float w, hipStream_t st);
+// frag.glsl:306-354 for every sample of the rows [..] in one kernel, brute-force scenes only (mode kBrute): per-sample radiance
+// (ray index ((yl*w + x)*spp + s), as the staged pipeline leaves it), to be resolved by launch_resolve
+hipError_t launch_path_brute(const DevScene& s, const DevCamera& cam, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows, uint32_t stripe_h,
+                             uint32_t stripe_step, uint32_t spp, uint32_t bounces, uint32_t seed, float4* d_radiance, hipStream_t st);
 // Interleaved shares -> image order (multi-slot rt_render / rt_trace_primary): `stage` holds n_shares blocks of
 // share_rows rows x row_words 32-bit words; share s owns the stripes s, s + n_shares, ... of stripe_h rows each.
 // Row y of the h-row frame is row (y / stripe_h / n_shares) * stripe_h + y % stripe_h of share (y / stripe_h) % n_shares.

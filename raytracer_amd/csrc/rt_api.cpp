@@ -213,6 +213,7 @@ struct rt_ctx {
     int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
     int primary_path = 0;       // primary rays: 0 auto, 1 tile kernel (k_primary), 2 ray generation + ray-buffer kernel
     int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
+    int fused_paths = 1;        // rt_render on brute-force scenes: 1 = the whole path loop in one kernel, 0 = the staged pipeline (RT_OPT_FUSED_PATHS)
     int frame_exchange = 0;     // multi-slot frames: 0 auto, 1 RCCL send/recv, 2 peer copies (RT_OPT_FRAME_EXCHANGE)
     Rccl rccl;
     int last_exchange = 0;      // what the last multi-slot frame used (1 RCCL, 2 peer copies; 0 = none yet)
@@ -638,6 +639,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) try {
         case RT_OPT_SAH_BINS:    if (v < 4 || v > 32) return fail(c, RT_E_INVALID, "RT_OPT_SAH_BINS in [4,32]"); c->sah_bins = (int)v; return RT_OK;
         case RT_OPT_SAH_TRAV:    if (v < 1 || v > 10000) return fail(c, RT_E_INVALID, "RT_OPT_SAH_TRAV in [1,10000] (hundredths)"); c->sah_trav_x100 = (int)v; return RT_OK;
         case RT_OPT_RAY_PACKETS: if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PACKETS: 0 off, 1 on"); c->ray_packets = (int)v; return RT_OK;
+        case RT_OPT_FUSED_PATHS: if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_FUSED_PATHS: 0 staged, 1 fused"); c->fused_paths = (int)v; return RT_OK;
         case RT_OPT_FRAME_EXCHANGE: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_FRAME_EXCHANGE: 0 auto, 1 RCCL, 2 peer copies"); c->frame_exchange = (int)v; return RT_OK;
         case RT_OPT_RAY_PAD:     if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PAD: 0 off, 1 on"); c->ray_pad = (int)v; return RT_OK;
         default: return fail(c, RT_E_INVALID, "unknown option key");
@@ -990,6 +992,17 @@ int rt_render(rt_ctx* c, uint32_t w, uint32_t h, uint32_t spp, uint32_t bounces,
         float4* rad = reinterpret_cast<float4*>(base + n * 96);
         uint32_t* rgba = in_place ? reinterpret_cast<uint32_t*>(shares) : reinterpret_cast<uint32_t*>(base + n * 112);
         const DevScene ds = c->dev_scene(r);
+        if (mode == kBrute && c->fused_paths) {
+            // the reference's own kind of scene (a few triangles, its brute-force loop): the whole path loop in one kernel
+            RT_HIP_SLOT(r, launch_path_brute(ds, c->cam, w, h, y0, rows, stripe_h, step, spp, bounces, seed, rad, r.stream));
+            RT_HIP_SLOT(r, launch_resolve(rad, npx, spp, nullptr, rgba, r.stream));
+            d_share[s] = rgba;
+            if (!gathered) {
+                RT_HIP_SLOT(r, hipMemcpyAsync(host_rgba8, rgba, npx * 4, hipMemcpyDeviceToHost, r.stream));
+                RT_HIP_SLOT(r, hipStreamSynchronize(r.stream));
+            }
+            return RT_OK;
+        }
         // segment 0: primary rays + their shading in one kernel (the primary rays and hits stay in registers)
         const uint32_t key0 = (uint32_t)((uint64_t)y0 * w * spp);
         if (primary_via_buffer(c)) {             // big tree: ray generation -> ray-buffer kernel -> first-segment shade

@@ -938,6 +938,30 @@ def test_rt_render_matches_oracle_frame():
         assert got[..., :3].mean() > 20                                   # the emissive panel lights the box
 
 
+@pytest.mark.parametrize("with_lights", [False, True])
+def test_fused_path_kernel_equals_the_staged_pipeline(with_lights):
+    """rt_render on a brute-force scene (the reference's Cornell box: 12 triangles + 3 spheres, frag.glsl's own loop): the one-kernel
+    path loop (RT_OPT_FUSED_PATHS 1, default) against the staged trace / shade kernels (0), byte for byte, on one slot and on
+    interleaved shares, for a ragged frame, one bounce and many; and against orc_render within the gamma LSB."""
+    tris, sph, _ = scenes.cornell()
+    lights = _lights2() if with_lights else None
+    w, h = 83, 37
+    cam = rt.default_camera(w / h)
+    for spp, bounces in ((3, 1), (4, 5), (10, 8)):
+        frames = []
+        for devs, fused in (((0,), 1), ((0,), 0), ((0, 0, 0), 1)):
+            with rt.Renderer(devs) as r:
+                r.set_option(rt.OPT_FUSED_PATHS, fused)
+                r.create_data(tris, sph, lights)
+                r.update_camera(cam)
+                frames.append(r.render(w, h, spp=spp, bounces=bounces, seed=4))
+        assert np.array_equal(frames[0], frames[1]), (spp, bounces, "fused vs staged")
+        assert np.array_equal(frames[0], frames[2]), (spp, bounces, "three slots")
+        _, want = oracle.render(oracle.Scene(tris, sph, lights), cam, w, h, spp, bounces, 4)
+        assert np.abs(frames[0].astype(np.int32) - want.astype(np.int32)).max() <= 1
+        assert frames[0][..., :3].mean() > 2                              # one bounce, no lights: only the emissive panel shows
+
+
 def test_adversarial_ties_and_epsilon_cases():
     """scripts/fuzz_ties.py: coplanar grids with shared edges / vertices, duplicated triangles, slivers, zero-area triangles,
     coincident spheres; rays aimed exactly at vertices and edge midpoints, in-plane and axis-parallel.  0 differing records
