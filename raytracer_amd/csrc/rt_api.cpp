@@ -160,6 +160,7 @@ struct Rccl {
     void* so = nullptr;
     bool tried = false;
     std::string why;                                   // why it cannot be used (after a failed attempt)
+    bool given_up = false;                             // RT_OPT_FRAME_EXCHANGE 0 (auto) fell back to peer copies for good
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -492,8 +493,9 @@ int frame_gather(rt_ctx* c, const FrameSplit& sp, uint32_t h, size_t row_bytes, 
     const size_t share_bytes = (size_t)sp.share_rows * row_bytes;
     Replica& r0 = c->reps[0];
     bool use_rccl = c->frame_exchange == 1;
-    if (c->frame_exchange == 0 && ns > 1 && distinct_devices(c)) {
+    if (c->frame_exchange == 0 && ns > 1 && !c->rccl.given_up && distinct_devices(c)) {
         use_rccl = rccl_prepare(c) == RT_OK;        // auto: RCCL when it is there, else peer copies (the reason stays in rccl.why)
+        if (!use_rccl) { c->rccl.given_up = true; if (c->rccl.why.empty()) c->rccl.why = c->err; }     // not tried again frame after frame
         c->err.clear();
     }
     const char* src = shares;                       // where launch_gather_rows reads the shares
@@ -503,6 +505,10 @@ int frame_gather(rt_ctx* c, const FrameSplit& sp, uint32_t h, size_t row_bytes, 
         Rccl& rc = c->rccl;
         // Grouped point-to-point: slot s sends its share once, over its own xGMI link to slot 0; no ring, no reduction.
         RT_RCCL(c, rc.GroupStart());
+        struct GroupGuard {                         // an error between GroupStart and GroupEnd must not leave RCCL in group mode
+            Rccl& rc; bool open = true;
+            ~GroupGuard() { if (open) (void)rc.GroupEnd(); }
+        } group{ rc };
         for (int s = 1; s < ns; ++s) {
             RT_RCCL(c, rc.Send(d_share[s], share_bytes, ncclUint8, 0, rc.comms[s], c->reps[s].stream));
             RT_RCCL(c, rc.Recv(shares + (size_t)s * share_bytes, share_bytes, ncclUint8, s, rc.comms[0], r0.stream));
@@ -515,6 +521,7 @@ int frame_gather(rt_ctx* c, const FrameSplit& sp, uint32_t h, size_t row_bytes, 
             RT_RCCL(c, rc.Recv(shares + share_bytes, share_bytes, ncclUint8, 0, rc.comms[0], r0.stream));
             src = shares + share_bytes;
         }
+        group.open = false;
         RT_RCCL(c, rc.GroupEnd());
         c->last_exchange = 1;
     } else {

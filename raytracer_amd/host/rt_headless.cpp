@@ -12,6 +12,8 @@
 // (src/application/Application.h:53-174) would between frames.
 //
 // usage: rt_headless [width height [out.ppm [spp bounces [mesh.obj|- [yaw_deg pitch_deg dolly]]]]]
+// RT_HEADLESS_DEVICES="0,1,2,3" (environment): the HIP device ordinals of the engine's slots -- with several, the frame is dealt
+// out in interleaved 8-row stripes and gathered on the first device (RT_OPT_FRAME_EXCHANGE); an ordinal may repeat.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -39,7 +41,18 @@ int main(int argc, char** argv) {
             spheres.clear();
         }
 
-        rt::Engine engine({0});
+        std::vector<int> devices;
+        if (const char* list = std::getenv("RT_HEADLESS_DEVICES")) {
+            for (const char* p = list; *p;) {
+                char* end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) throw std::runtime_error(std::string("RT_HEADLESS_DEVICES: not a list of device ordinals: ") + list);
+                devices.push_back((int)v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (devices.empty()) devices.push_back(0);
+        rt::Engine engine(devices);
         engine.upload(tris, spheres, lights);
         // VkRenderer::VkRenderer (VkRenderer.cpp:3-12): position (0,4,1), lookAt (0,0,1), up (0,0,-1), vfov 45, near 0.1, far 100
         rt::Camera camera({0.0f, 4.0f, 1.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, -1.0f}, 45.0f, (float)w / (float)h, 0.1f, 100.0f);

@@ -696,6 +696,14 @@ def test_cpp_headless_harness(tmp_path):
     lit = int(p.stdout.split(" non-black")[0].split()[-1])
     assert 100 < lit <= 64 * 48              # light patch + surfaces whose one bounce reaches it
     assert len(out.read_bytes()) == len(b"P6\n64 48\n255\n") + 64 * 48 * 3
+    # the same frame from an engine of three slots (interleaved stripes gathered on the first device), through the C++ wrapper
+    one = out.read_bytes()
+    p = subprocess.run([exe, "64", "48", str(out), "2", "2", str(obj)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, RT_HEADLESS_DEVICES="0,0,0"))
+    assert p.returncode == 0, p.stderr
+    assert out.read_bytes() == one
+    p = subprocess.run([exe, "64", "48", str(out)], capture_output=True, text=True, timeout=120, env=dict(os.environ, RT_HEADLESS_DEVICES="0,x"))
+    assert p.returncode == 1 and "RT_HEADLESS_DEVICES" in p.stderr
     p = subprocess.run([exe, "64", "48", str(out), "2", "2", str(tmp_path / "missing.obj")], capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "rt_load_obj failed" in p.stderr
     p = subprocess.run([exe, "0", "0", str(out)], capture_output=True, text=True, timeout=120)
