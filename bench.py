@@ -105,7 +105,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_GROUP=1: a process group even for ONE rank, so that the exchange code N ranks run -- asynchronous RCCL gather
+    # into alternating buffers, drain, barrier, max over ranks -- executes on a one-GPU box (tests/test_gpu_ranks.py)
+    grouped = world > 1 or os.environ.get("RT_BENCH_FORCE_GROUP") == "1"
+    if grouped and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -134,8 +144,8 @@ def main():
     thr, rad = f32(n_local * 4), f32(n_local * 4)
     # RGBA8 framebuffer stripes of this rank; two of them for N > 1, so that the gather of frame k can run while frame k + 1
     # is traced into the other one
-    fbs = [torch.empty(n_px, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
-    gidx = rd.gather_index(plan, dev) if world > 1 else None
+    fbs = [torch.empty(n_px, dtype=torch.int32, device=dev) for _ in range(2 if grouped else 1)]
+    gidx = rd.gather_index(plan, dev) if grouped else None
     state = {"k": 0, "ticket": None, "frame": None}
     cur_fb = lambda: fbs[state["k"] % len(fbs)]
     stream = torch.cuda.current_stream()
@@ -164,13 +174,13 @@ def main():
     # RCCL, gather to rank 0: the exchange of frame k is asynchronous (RCCL's own stream) and overlaps the kernels of frame
     # k + 1; frame k is complete on rank 0 -- waited for and de-interleaved -- by the end of step k + 1, the last one by the
     # drain inside the timed region.  RT_BENCH_GATHER_SYNC=1 keeps the blocking form for A/B runs.
-    pipelined = world > 1 and backend == "nccl" and not gather_all and os.environ.get("RT_BENCH_GATHER_SYNC") != "1"
+    pipelined = grouped and backend == "nccl" and not gather_all and os.environ.get("RT_BENCH_GATHER_SYNC") != "1"
     fg = rd.FrameGather(plan, (W,), torch.int32, dev, 0, gidx) if pipelined else None
 
     def stage_gather():
         # per-rank RGBA8 stripes -> the frame on rank 0 (what shows it): each rank sends its 4 MB once, over its own
         # xGMI link to rank 0 (RCCL send/recv), and rank 0 de-interleaves the stripes with one index_select
-        if world == 1:
+        if not grouped:
             state["frame"] = cur_fb()
             return
         mine = cur_fb().view(plan.padded_rows, W)
@@ -213,7 +223,7 @@ def main():
     drain()
     ne = len(stages) + 1
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(ne)] for _ in range(args.steps)]
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -224,11 +234,11 @@ def main():
             ev[k][j + 1].record(stream)
         state["k"] += 1
     drain()                                              # the last frame's gather + de-interleave belong to the K steps
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -242,7 +252,7 @@ def main():
     unfused_primary()                                    # primary rays / hits in HBM for the parity sample
     torch.cuda.synchronize()
     if rank != 0:
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return
     frame_np = frame.reshape(-1)[: W * H].cpu().numpy()
@@ -308,9 +318,9 @@ def main():
                            "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
         "frame_sha256": frame_sha,       # RGBA8 framebuffer: identical for every N (decomposition-invariant RNG keys)
         "frame_lit_pixels": lit_pixels,
-        "ranks": {"world_size": dist.get_world_size() if world > 1 else 1,
-                  "backend": (dist.get_backend() if world > 1 else None),        # "nccl" = RCCL over xGMI
-                  "exchange": None if world == 1 else ("all_gather" if gather_all else "gather to rank 0"),
+        "ranks": {"world_size": dist.get_world_size() if grouped else 1,
+                  "backend": (dist.get_backend() if grouped else None),          # "nccl" = RCCL over xGMI
+                  "exchange": None if not grouped else ("all_gather" if gather_all else "gather to rank 0"),
                   "exchange_overlaps_next_frame": bool(pipelined)},
         # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints
         # (the packet form of the tile kernel keeps its stack in a register: no LDS)
@@ -409,7 +419,7 @@ def main():
         out["with_transfers"] = res
         r.host_free(p_rays); r.host_free(p_hits)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

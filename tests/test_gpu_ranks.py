@@ -49,6 +49,21 @@ def test_bench_two_ranks_self_launched_give_the_single_rank_frame():
     assert allg["ranks"]["exchange"] == "all_gather" and allg["frame_sha256"] == one["frame_sha256"]
 
 
+def test_bench_exchange_code_on_rccl_with_one_rank():
+    """RT_BENCH_FORCE_GROUP=1: bench.py with a one-rank "nccl" (= RCCL) process group on the GPU -- the pipelined exchange exactly as N
+    ranks run it (asynchronous gather of frame k into alternating buffers while frame k + 1 is traced, drain, barrier, max over
+    ranks) -- and the blocking and all-gather forms: same frame as the plain run."""
+    base = [sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    one = _run(base, {})
+    for extra, overlapped, exchange in (({}, True, "gather to rank 0"), ({"RT_BENCH_GATHER_SYNC": "1"}, False, "gather to rank 0"),
+                                        ({"RT_BENCH_GATHER": "all"}, False, "all_gather")):
+        got = _run(base, dict(extra, RT_BENCH_FORCE_GROUP="1"))
+        assert got["ranks"]["backend"] == "nccl" and got["ranks"]["world_size"] == 1
+        assert got["ranks"]["exchange"] == exchange and got["ranks"]["exchange_overlaps_next_frame"] is overlapped
+        assert got["frame_sha256"] == one["frame_sha256"], extra
+        assert got["ms_per_step"] < 3 * one["ms_per_step"]
+
+
 def test_c4_ray_ranges_over_two_and_three_ranks_give_the_single_rank_hits():
     args = ["--soup", "300000", "--rays", "2000003", "--steps", "2"]          # a ray count no rank count divides
     one = _run([sys.executable, "scripts/run_c4_ranks.py"] + args, {})
