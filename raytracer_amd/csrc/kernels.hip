@@ -1386,8 +1386,10 @@ __global__ __launch_bounds__(kBlock) void k_bin_count(const rt_ray* __restrict__
 // 1,024 rows whatever the buffer's size -- a tenth of a 4 Mi-ray call's binning; profiles/r04e_c4_kernels_by_ray_count.txt.)
 constexpr uint32_t kColBins = 16, kColSegs = kBlock / kColBins;
 __global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ hist, uint32_t n_blocks, uint32_t bins, uint32_t* __restrict__ totals,
-                                                        uint32_t* __restrict__ meta /* [1] += non-empty (block, bin) pairs; null = do not count */) {
+                                                        uint32_t* __restrict__ meta /* [1] += non-empty (block, bin) pairs; null = do not count */,
+                                                        const uint32_t* __restrict__ on /* null, or: return at once when *on == 0 */) {
     __shared__ uint32_t part[kColSegs][kColBins];
+    if (on && *on == 0u) return;
     const uint32_t bl = threadIdx.x % kColBins, seg = threadIdx.x / kColBins;
     const uint32_t b = blockIdx.x * kColBins + bl;
     const uint32_t per = (n_blocks + kColSegs - 1) / kColSegs;
@@ -1427,8 +1429,9 @@ __global__ __launch_bounds__(kBlock) void k_bin_columns(uint32_t* __restrict__ h
 // totals[bin] -> start of the bin in the permutation (exclusive scan, one block)
 // decide: 1 = this launch takes the permute / keep decision (meta[0]) from the pair count; 0 = leaves it as it is
 __global__ __launch_bounds__(kBlock) void k_bin_scan(uint32_t* __restrict__ totals, uint32_t bins, uint32_t* __restrict__ meta, uint64_t n,
-                                                     uint32_t min_run, int decide) {
-    if (decide && threadIdx.x == 0) meta[0] = (min_run == 0u || n < (uint64_t)min_run * meta[1]) ? 1u : 0u;   // permute?
+                                                     uint32_t min_run, int decide /* 2 = the decision is taken already: nothing to do when it is 0 */) {
+    if (decide == 2 && meta[0] == 0u) return;
+    if (decide == 1 && threadIdx.x == 0) meta[0] = (min_run == 0u || n < (uint64_t)min_run * meta[1]) ? 1u : 0u;   // permute?
     __shared__ uint32_t part[kBlock];
     const uint32_t per = (bins + kBlock - 1) / kBlock;
     const uint32_t lo = threadIdx.x * per;
@@ -1472,10 +1475,46 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const rt_ray* __restrict
 // the bin first (65 streams per block, runs of ~1,000 entries) and by the whole bin second, on an array that is
 // grouped by the upper bits already, so a block of the second level meets ~100 bins and writes runs of ~600 entries.
 // The bin of every ray is computed once (16 bits per ray) instead of re-reading the 32-byte rays.
+// Is the buffer grouped by origin already (camera-ordered bounce rays are)?  Decided from every kBinProbeStride-th (64th) ray before
+// anything else runs: a buffer that keeps its order then costs a fraction of a counting pass instead of a whole one (C5: two
+// bounce buffers of 132 M slots, 1.0 ms each just to find out that nothing is to be done).  meta[2] += non-empty (block, cell)
+// pairs among the samples, meta[3] += samples; k_bin_decide sets meta[0] = 1 (permute) when a pair holds fewer than
+// min_run / stride samples on average, and every later kernel of the sort returns at once when it is 0.
+constexpr uint32_t kBinProbeStride = 64;
+__global__ __launch_bounds__(kBlock) void k_bin_probe(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block, BinGrid g,
+                                                      uint32_t* __restrict__ meta) {
+    __shared__ uint32_t h[kBins];
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) h[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
+    uint32_t mine = 0;
+    for (uint64_t i = lo + (uint64_t)threadIdx.x * kBinProbeStride; i < hi; i += (uint64_t)kBlock * kBinProbeStride) { atomicAdd(&h[ray_bin(rays, i, g)], 1u); ++mine; }
+    __syncthreads();
+    uint32_t pairs = 0;
+    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) pairs += h[b] != 0u;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { pairs += __shfl_down(pairs, off, 64); mine += __shfl_down(mine, off, 64); }
+    // ONE pair of atomics per block (through LDS), not per wave: thousands of atomics on one address serialise in their L2
+    // channel -- with one per wave this kernel took 100 us whatever the buffer's size
+    __shared__ uint32_t red[2][kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pairs; red[1][threadIdx.x >> 6] = mine; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t p = 0, m = 0;
+        for (int k = 0; k < kBlock / 64; ++k) { p += red[0][k]; m += red[1][k]; }
+        if (p) atomicAdd(&meta[2], p);
+        if (m) atomicAdd(&meta[3], m);
+    }
+}
+__global__ void k_bin_decide(uint32_t* __restrict__ meta, uint32_t min_run) {
+    if (threadIdx.x == 0) meta[0] = (min_run == 0u || (uint64_t)meta[3] * kBinProbeStride < (uint64_t)min_run * meta[2]) ? 1u : 0u;
+}
+
 __global__ __launch_bounds__(kBlock) void k_bin2_count(const rt_ray* __restrict__ rays, uint64_t n, uint64_t per_block, BinGrid g,
                                                        uint16_t* __restrict__ keys, uint32_t* __restrict__ hist_hi /* [block][kBinsHi] */,
                                                        uint32_t* __restrict__ meta) {
     __shared__ uint32_t h[kBins];
+    if (meta[0] == 0u) return;                                               // k_bin_probe / k_bin_decide: the buffer keeps its order
     for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) h[b] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = (lo + per_block < n) ? lo + per_block : n;
@@ -1485,12 +1524,7 @@ __global__ __launch_bounds__(kBlock) void k_bin2_count(const rt_ray* __restrict_
         atomicAdd(&h[b], 1u);
     }
     __syncthreads();
-    // non-empty (block, bin) pairs -> the coherence decision of k_bin_scan; upper-level histogram row
-    uint32_t pairs = 0;
-    for (uint32_t b = threadIdx.x; b < kBins; b += kBlock) pairs += h[b] != 0u;
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pairs += __shfl_down(pairs, off, 64);
-    if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(&meta[1], pairs);
+    // upper-level histogram row (the coherence decision was taken by k_bin_probe / k_bin_decide before this kernel)
     if (threadIdx.x < kBinsHi) {
         uint32_t sum = 0;
         const uint32_t first = threadIdx.x << kBinLoBits, last = min(first + (1u << kBinLoBits), kBins);
@@ -1613,7 +1647,7 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
     if (e != hipSuccess) return e;
     if (!two_level) {
         hipLaunchKernelGGL(k_bin_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist);
-        hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, meta);
+        hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, meta, (const uint32_t*)nullptr);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 1);
         hipLaunchKernelGGL(k_bin_scatter, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, hist, totals, meta, perm);
         return hipGetLastError();
@@ -1627,13 +1661,15 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
     uint16_t* tmp_key = reinterpret_cast<uint16_t*>(d_scratch + off_tmp);
     uint32_t* hist_hi = hist;                                                // rows of kBinsHi words; the full-width rows reuse the area afterwards
     uint32_t* totals_hi = totals;
+    hipLaunchKernelGGL(k_bin_probe, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, meta);
+    hipLaunchKernelGGL(k_bin_decide, dim3(1), dim3(64), 0, st, meta, min_run);
     hipLaunchKernelGGL(k_bin2_count, dim3(n_blocks), dim3(kBlock), 0, st, d_rays, n, per_block, g, keys, hist_hi, meta);
-    hipLaunchKernelGGL(k_bin_columns, dim3((kBinsHi + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist_hi, n_blocks, kBinsHi, totals_hi, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals_hi, kBinsHi, meta, n, min_run, 1);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBinsHi + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist_hi, n_blocks, kBinsHi, totals_hi, (uint32_t*)nullptr, (const uint32_t*)meta);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals_hi, kBinsHi, meta, n, min_run, 2);
     hipLaunchKernelGGL(k_bin2_scatter_hi, dim3(n_blocks), dim3(kBlock), 0, st, keys, n, per_block, hist_hi, totals_hi, meta, tmp_idx, tmp_key);
     hipLaunchKernelGGL(k_bin2_count_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, n, per_block, meta, hist);
-    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 0);
+    hipLaunchKernelGGL(k_bin_columns, dim3((kBins + kColBins - 1) / kColBins), dim3(kBlock), 0, st, hist, n_blocks, kBins, totals, (uint32_t*)nullptr, (const uint32_t*)meta);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kBlock), 0, st, totals, kBins, meta, n, min_run, 2);
     hipLaunchKernelGGL(k_bin2_scatter_keys, dim3(n_blocks), dim3(kBlock), 0, st, tmp_key, tmp_idx, n, per_block, hist, totals, meta, perm);
     return hipGetLastError();
 }
