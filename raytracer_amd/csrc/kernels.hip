@@ -613,7 +613,7 @@ void k_trace_packet(DevScene s, const rt_ray* __restrict__ rays, uint64_t n, con
 constexpr int kSecondStepLanes = 36;      // lanes on interior nodes from which a round takes a second interior step
 template <int MODE, bool ANY, bool COUNT, bool CAPPED>
 __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
-                                                        uint32_t strip, int refill, int tth,
+                                                        uint32_t strip, int refill, int tth, int refill_perm /* both thresholds (tth << 8 | refill) for a buffer that IS handed out permuted */,
                                                         unsigned long long* __restrict__ work /* 8 chunk cursors + mask, kCursorStride apart, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
                                                         const uint32_t* __restrict__ perm_on /* device flag, null = on */,
@@ -625,6 +625,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
     if (perm && perm_on && *perm_on == 0u) perm = nullptr;             // launch_bin found the buffer coherent already
+    if (perm && refill_perm) { refill = refill_perm & 0xff; tth = refill_perm >> 8; }
     // Wave-uniform state of the chunk being handed out, all 32 bits wide so that it lives in SGPRs and the per-round tests are
     // scalar compares (a 64-bit cursor / end pair needs v_cmp_lt_u64: the compiler then keeps the whole chain -- cursor, end,
     // the eighth's number, the mask of exhausted eighths -- in six VGPRs of the 72 this kernel has): chunk number, rays of
@@ -1692,6 +1693,10 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
     dim3 b(kBlock);
     float4* hits = reinterpret_cast<float4*>(d_hits);
     const int rf = refill & 0xff, tth = refill >> 8;
+    // Large permuted buffers (random rays sorted by origin cell, 2^25 rays and more) do better with refills in bigger batches and
+    // an earlier triangle block: 10 M-triangle soup, 64 Mi rays 24.8 -> 23.7 ms.  Not so smaller ones (8 Mi: 4.05 -> 4.22 ms, the
+    // launch is HBM-bound) nor buffers that keep their order (C5's bounce rays: 48.6 -> 50.7 ms): profiles/r04u_refill_sweeps.txt.
+    const int rf_perm = (d_perm && sc.refill_perm && n >= (1ull << 25)) ? sc.refill_perm : 0;
     if (mode != kBrute && strip >= 64) {
         // strip kernel: persistent waves, as many blocks as the chip holds at once (LDS-limited), never more than
         // there are chunks.  The chunk cursors live in the caller's scratch (sc.work), zeroed on the stream.
@@ -1719,7 +1724,7 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));
         if (sc.max_blocks) blocks = std::min<uint64_t>(blocks, sc.max_blocks);
         dim3 g((uint32_t)blocks);
-#define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
+#define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, rf_perm, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M, P) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P); else RT_LAUNCH(M, true, false, P); } \
                                else         { if (count) RT_LAUNCH(M, false, true, P); else RT_LAUNCH(M, false, false, P); } } while (0)
         if (mode == kBvh4q) { if (capped) RT_LAUNCH_M(kBvh4q, true); else RT_LAUNCH_M(kBvh4q, false); } else RT_LAUNCH_M(kBvh2, false);

@@ -319,6 +319,7 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         set = (int)(r.scratch_seq++ % kSpillSlots);
         sc.work = r.d_counters + kCountersPad + (size_t)set * kWorkWords;
         sc.lds_cap = c->lds_stack;
+        if (c->refill == (16 | (12 << 8))) sc.refill_perm = 32 | (8 << 8);      // the default thresholds: large permuted buffers get their own (kernels.hip launch_trace); an explicit RT_OPT_REFILL holds for all
         // Structures that do not fit the L2s (the ones whose rays get binned), buffers below 2^25 rays: the rays in flight at
         // once are a large part of the buffer, so the region of the scene they touch outgrows the caches (10 M-triangle soup,
         // 8 Mi rays: L2 hit 52 %, HBM 5.8 TB/s -- the launch is HBM-bound; profiles/r04j_c4_8mi_summary.md).  Fewer resident

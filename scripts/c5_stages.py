@@ -12,6 +12,8 @@ n = w * h * spp
 dev = torch.device("cuda", 0)
 f32 = lambda k: torch.empty(n * k, dtype=torch.float32, device=dev)
 with rt.Renderer((0,)) as r:
+    for kv in filter(None, os.environ.get('RT_OPTS', '').split(',')):      # tuning sweeps: key=value pairs of rt_set_option
+        r.set_option(int(kv.split('=')[0]), int(kv.split('=')[1]))
     r.create_data(tris); r.update_camera(cam)
     ra, rb, hits, thr, rad = f32(8), f32(8), f32(4), f32(4), f32(4)
     fb = torch.empty(w * h, dtype=torch.int32, device=dev)
