@@ -1331,12 +1331,29 @@ __global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rt_r
         c[1] += __shfl(C.y, (int)(first + k), 64);
         c[2] += __shfl(C.z, (int)(first + k), 64);
     }
+    const float fs = (float)spp;
+    c[0] = c[0] / fs; c[1] = c[1] / fs; c[2] = c[2] / fs;
+    // The gamma step (three powf per pixel) was this kernel's largest cost, run by one lane in spp: now the lanes of a pixel
+    // share it -- lane j of the pixel takes channel j (channels q*spp + j in pass q when spp < 3), ONE powf per lane and pass,
+    // and the pixel's first lane collects the bytes.  Same function on the same value, so the same byte as to_rgba8.
+    uint32_t px = 0xff000000u;
+    if (rgba) {                                                            // wave-uniform
+        const uint32_t j = lane - first, passes = (3u + spp - 1u) / spp;
+        for (uint32_t q = 0; q < passes; ++q) {
+            const uint32_t ch = q * spp + j;
+            const float vin = ch == 0u ? c[0] : (ch == 1u ? c[1] : c[2]);
+            float v = powf(vin, 1.0f / 2.6f);
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            if (!(v == v)) v = 0.0f;
+            const uint32_t byte = (uint32_t)(v * 255.0f + 0.5f);
+            for (uint32_t k = 0; k < spp && q * spp + k < 3u; ++k)       // wave-uniform trip count
+                px |= (uint32_t)__shfl((int)byte, (int)(first + k), 64) << (8u * (q * spp + k));
+        }
+    }
     if (i < n && lane == first) {
         const uint64_t p = i / spp;
-        const float fs = (float)spp;
-        c[0] = c[0] / fs; c[1] = c[1] / fs; c[2] = c[2] / fs;
         if (lin) lin[p] = make_float4(c[0], c[1], c[2], 1.0f);
-        if (rgba) rgba[p] = to_rgba8(c[0], c[1], c[2]);
+        if (rgba) rgba[p] = px;
     }
 }
 
