@@ -143,6 +143,9 @@ void rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);   /* never NULL; "" when the last call succeeded */
 int  rt_set_option(rt_ctx* ctx, int key, int64_t value);
 int  rt_num_slots(const rt_ctx* ctx);
+/* How the last frame of a context with several slots (rt_render / rt_trace_primary) was gathered on slot 0:
+ * 1 = RCCL send / recv, 2 = peer copies, 0 = no such frame yet (RT_OPT_FRAME_EXCHANGE).  No counterpart in the reference. */
+int  rt_frame_exchange_used(const rt_ctx* ctx);
 
 /* ---- scene upload (once) -----------------------------------------------------------------------
  * Replaces VkRenderer::createData's three SSBO uploads (src/vulkan/VkRenderer.cpp:260-326).  Takes

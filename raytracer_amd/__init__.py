@@ -177,6 +177,11 @@ class Renderer:
     def num_slots(self):
         return self._lib.rt_num_slots(self._ctx)
 
+    @property
+    def frame_exchange_used(self):
+        """1 = the last multi-slot frame was gathered over RCCL, 2 = by peer copies, 0 = none yet."""
+        return self._lib.rt_frame_exchange_used(self._ctx)
+
     def set_option(self, key, value):
         self._check(self._lib.rt_set_option(self._ctx, key, int(value)))
 

@@ -38,6 +38,7 @@ SYMBOLS = [
     ("rt_last_error", C.c_char_p, [_P]),
     ("rt_set_option", _I, [_P, _I, C.c_int64]),
     ("rt_num_slots", _I, [_P]),
+    ("rt_frame_exchange_used", _I, [_P]),
     ("rt_scene_upload", _I, [_P, _P, _U32, _U32, _P, _U32, _U32, _P, _U32, _U32]),
     ("rt_scene_stats_get", _I, [_P, C.POINTER(rt_scene_stats)]),
     ("rt_bvh_build_host", _I, [_P, _U32, _U32, _I, _I, _I, _I, C.POINTER(rt_scene_stats), _P, _U64, _P]),

@@ -629,6 +629,8 @@ const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null c
 
 int rt_num_slots(const rt_ctx* c) { return c ? (int)c->reps.size() : 0; }
 
+int rt_frame_exchange_used(const rt_ctx* c) { return c ? c->last_exchange : 0; }
+
 int rt_set_option(rt_ctx* c, int key, int64_t v) try {
     if (!c) return RT_E_INVALID;
     c->err.clear();

@@ -546,11 +546,13 @@ def test_rccl_frame_exchange_inside_the_library():
         for _ in range(2):                                                    # second call: communicator and staging reused
             assert np.array_equal(a.render(w, h, spp=4, bounces=3, seed=5), b.render(w, h, spp=4, bounces=3, seed=5))
             assert a.trace_primary(w, h).tobytes() == b.trace_primary(w, h).tobytes()
+        assert b.frame_exchange_used == 1 and a.frame_exchange_used == 0      # RCCL really carried b's frames
         two.set_option(rt.OPT_FRAME_EXCHANGE, 1)
         with pytest.raises(RuntimeError, match="distinct device ordinals"):
             two.render(w, h, spp=4, bounces=3, seed=5)
         two.set_option(rt.OPT_FRAME_EXCHANGE, 0)
         assert np.array_equal(two.render(w, h, spp=4, bounces=3, seed=5), a.render(w, h, spp=4, bounces=3, seed=5))
+        assert two.frame_exchange_used == 2                                   # repeated ordinals: peer copies
         with pytest.raises(RuntimeError):
             two.set_option(rt.OPT_FRAME_EXCHANGE, 3)
 
