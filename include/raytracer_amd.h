@@ -93,6 +93,12 @@ enum {
                                loaded on first use; needs distinct device ordinals -- RCCL refuses a communicator with a GPU twice);
                                2 = hipMemcpyPeerAsync (plain device copies when the ordinals repeat);
                                0 auto (default) = 1 when all ordinals differ and RCCL loads, else 2.  Same frame in every case. */
+    RT_OPT_RAY_QUEUE = 19,  /* ray-buffer kernel, BVH4q nodes: 1 = every wave keeps a queue of 32 prepared rays (origin, direction, interval,
+                               slab constants, index) in LDS, filled by half the wave at once; idle lanes start their next ray from it
+                               (refills from 6 idle lanes on instead of 16, and 12 instead of 20 stack entries in LDS, unless
+                               RT_OPT_REFILL / RT_OPT_LDS_STACK say otherwise).  0 = idle lanes load and prepare their next ray
+                               themselves.  2 auto (default) = 1 for launches whose rays are not binned (structures the L2s serve),
+                               else 0.  Results are unaffected. */
     RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for
                                measuring what it protects against only: rays that start hundreds of scene extents away
                                then lose hits the reference loop finds (tests/test_gpu_parity.py, far-origin test). */

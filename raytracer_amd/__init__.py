@@ -43,6 +43,7 @@ OPT_SAH_BINS, OPT_SAH_TRAV = 12, 13
 OPT_RAY_PACKETS = 15
 OPT_FRAME_EXCHANGE = 16
 OPT_FUSED_PATHS = 18
+OPT_RAY_QUEUE = 19
 NOALLOC_MAX_RAYS = 1 << 22
 TRAVERSAL_AUTO, TRAVERSAL_BRUTE, TRAVERSAL_BVH2, TRAVERSAL_BVH4Q = 0, 1, 2, 3
 TRAVERSAL_BVH = TRAVERSAL_BVH4Q

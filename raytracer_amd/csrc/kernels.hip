@@ -611,17 +611,28 @@ void k_trace_packet(DevScene s, const rt_ray* __restrict__ rays, uint64_t n, con
 #define RT_STRIP_ATTR
 #endif
 constexpr int kSecondStepLanes = 36;      // lanes on interior nodes from which a round takes a second interior step
-template <int MODE, bool ANY, bool COUNT, bool CAPPED>
+// QUEUE: a staged ray queue per wave in LDS (behind the stacks, at int offset q_off).  Whenever it is empty the lower half of the
+// wave loads the next kQueue rays and computes their slab constants -- 32 lanes at work, whatever the wave's traversal state --
+// and an idle lane then starts its next ray with four ds_read_b128 instead of a global load + make_slab executed for a
+// handful of lanes.  That makes a refill cheap enough to run at a threshold of a few idle lanes instead of 16.
+// Entry = 4 float4 in planes [plane][slot]: (o, tmin) (d, tmax) (idir, 2m) (entry constants, ray index); n < 2^32.
+constexpr int kQueue = 32;
+constexpr size_t kQueueBytesPerBlock = (size_t)(kBlock / 64) * 4 * kQueue * sizeof(float4);
+template <int MODE, bool ANY, bool COUNT, bool CAPPED, bool QUEUE = false>
 __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s, const rt_ray* __restrict__ rays, uint64_t n,
                                                         uint32_t strip, int refill, int tth, int refill_perm /* both thresholds (tth << 8 | refill) for a buffer that IS handed out permuted */,
                                                         unsigned long long* __restrict__ work /* 8 chunk cursors + mask, kCursorStride apart, 0 at launch */,
                                                         const uint32_t* __restrict__ perm /* hand-out order or null */,
                                                         const uint32_t* __restrict__ perm_on /* device flag, null = on */,
                                                         int* __restrict__ spill_base /* CAPPED: [entry][thread of the launch] */, int lds_cap,
+                                                        int q_off /* QUEUE: ints from the start of LDS to the ray queues */,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                         unsigned long long* counters) {
     extern __shared__ int stack[];
     int* stk = stack + threadIdx.x;
+    float4* const qw = reinterpret_cast<float4*>(stack + (QUEUE ? q_off : 0)) + (threadIdx.x >> 6) * (4 * kQueue);   // this wave's queue
+    uint32_t q_head = 0, q_avail = 0;                                  // wave-uniform: next slot to hand out, slots left
+    uint32_t my32 = 0;                                                 // QUEUE: the ray's index (32 bits)
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
     if (perm && perm_on && *perm_on == 0u) perm = nullptr;             // launch_bin found the buffer coherent already
@@ -656,7 +667,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         const bool idle = node == kDone && pend == 0;
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
-        if (cur >= lim && more && n_idle >= refill) {
+        if (cur >= lim && more && (QUEUE ? q_avail == 0u : n_idle >= refill)) {
             // draw the next chunk: own eighth of the buffer first (one cursor per XCD, so that an XCD's L2 sees one
             // contiguous -- with binning: spatially compact -- part of the rays), then the other eighths
             cur = lim = 0;
@@ -687,6 +698,51 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                 q = (q + (uint32_t)__builtin_ctz(rot)) & 7u;
             }
         }
+        if (QUEUE) {
+            if (q_avail == 0u && cur < lim) {
+                // stage the next rays of the chunk: lane l < cnt takes ray cur + l, whatever else it is doing
+                const uint32_t lane = threadIdx.x & 63u;
+                const uint32_t left = lim - cur, cnt = left < (uint32_t)kQueue ? left : (uint32_t)kQueue;
+                if (lane < cnt) {
+                    const uint64_t cand = (uint64_t)chunk * strip + cur + lane;
+                    const uint32_t idx = perm ? perm[cand] : (uint32_t)cand;
+                    const float4* rp = reinterpret_cast<const float4*>(rays + idx);
+                    const float4 r0 = rp[0], r1 = rp[1];
+                    const Slab ns = make_slab<MODE>(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), s.ray_pad);
+                    qw[lane] = r0;
+                    qw[kQueue + lane] = r1;
+                    qw[2 * kQueue + lane] = make_float4(ns.ix, ns.iy, ns.iz, ns.m2);
+                    qw[3 * kQueue + lane] = make_float4(ns.ex, ns.ey, ns.ez, __uint_as_float(idx));
+                }
+                cur += cnt; q_head = 0u; q_avail = cnt;
+            }
+            if (q_avail != 0u && n_idle >= refill) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+                if (idle && rank < q_avail) {
+                    const float4* qe = qw + (q_head + rank);
+                    const float4 r0 = qe[0], r1 = qe[kQueue], a = qe[2 * kQueue], e = qe[3 * kQueue];
+                    o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
+                    my32 = __float_as_uint(e.w);
+                    tmin0 = fmaxf(tmin, 0.0f);
+                    b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
+                    bool go = tmax > tmin;
+                    if (COUNT && go) ++n_mine;
+                    if (go) {
+                        spheres_pass<COUNT>(s, o, d, tmin, b, c);
+                        go = !(ANY && b.t < tmax) && s.n_nodes != 0;
+                    }
+                    if (go) {
+                        sl.ix = a.x; sl.iy = a.y; sl.iz = a.z; sl.m2 = a.w; sl.ex = e.x; sl.ey = e.y; sl.ez = e.z;
+                        node = 0; sp = 1;
+                    } else {
+                        if (ANY) occ[my32] = b.t < tmax ? 1 : 0;
+                        else     hits[my32] = pack_hit(b, tmax);
+                    }
+                }
+                const uint32_t took = (uint32_t)n_idle < q_avail ? (uint32_t)n_idle : q_avail;
+                q_head += took; q_avail -= took;
+            }
+        } else
         if (cur < lim && n_idle >= refill) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             if (idle && cur + rank < lim) {
@@ -715,7 +771,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         }
         const bool live = !(node == kDone && pend == 0);
         if (__ballot(live) == 0ull) {
-            if (cur >= lim && !more) break;
+            if (cur >= lim && !more && q_avail == 0u) break;
             continue;
         }
         // if-if scheduling with one postponed leaf per lane: per round every lane does at most ONE interior
@@ -785,8 +841,9 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             }
         }
         if (live && node == kDone && pend == 0) {
-            if (ANY) occ[my] = b.t < tmax ? 1 : 0;
-            else     hits[my] = pack_hit(b, tmax);
+            const uint64_t at = QUEUE ? (uint64_t)my32 : my;
+            if (ANY) occ[at] = b.t < tmax ? 1 : 0;
+            else     hits[at] = pack_hit(b, tmax);
         }
     }
     if (COUNT) {
@@ -1732,7 +1789,11 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         const int lds_cap = sc.lds_cap;
         int* d_spill = sc.spill;
         const bool capped = mode == kBvh4q && d_spill && lds_cap >= 2 && s.stack_depth + 2 > (uint32_t)lds_cap;
-        const size_t lds = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
+        const size_t lds_stack = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
+        // the staged ray queues sit behind the stacks (BVH4q, ray indices of 32 bits)
+        const bool queue = sc.queue && mode == kBvh4q && n < (1ull << 32);
+        const int q_off = (int)(lds_stack / sizeof(int));
+        const size_t lds = lds_stack + (queue ? kQueueBytesPerBlock : 0);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
         const uint64_t n_chunks = (n + strip - 1) / strip;
         if (n_chunks + 8 > 0xFFFFFFFFull) return hipErrorInvalidValue;      // the kernel counts chunks in 32 bits (2^38 rays at the smallest chunk)
@@ -1741,10 +1802,13 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));
         if (sc.max_blocks) blocks = std::min<uint64_t>(blocks, sc.max_blocks);
         dim3 g((uint32_t)blocks);
-#define RT_LAUNCH(M, A, C, P) hipLaunchKernelGGL((k_trace_strip<M, A, C, P>), g, b, lds, st, s, d_rays, n, strip, rf, tth, rf_perm, work, d_perm, d_perm_on, d_spill, lds_cap, hits, d_occ, d_counters)
-#define RT_LAUNCH_M(M, P) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P); else RT_LAUNCH(M, true, false, P); } \
-                               else         { if (count) RT_LAUNCH(M, false, true, P); else RT_LAUNCH(M, false, false, P); } } while (0)
-        if (mode == kBvh4q) { if (capped) RT_LAUNCH_M(kBvh4q, true); else RT_LAUNCH_M(kBvh4q, false); } else RT_LAUNCH_M(kBvh2, false);
+#define RT_LAUNCH(M, A, C, P, Q) hipLaunchKernelGGL((k_trace_strip<M, A, C, P, Q>), g, b, lds, st, s, d_rays, n, strip, rf, tth, rf_perm, work, d_perm, d_perm_on, d_spill, lds_cap, q_off, hits, d_occ, d_counters)
+#define RT_LAUNCH_M(M, P, Q) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P, Q); else RT_LAUNCH(M, true, false, P, Q); } \
+                                  else         { if (count) RT_LAUNCH(M, false, true, P, Q); else RT_LAUNCH(M, false, false, P, Q); } } while (0)
+        if (mode == kBvh4q) {
+            if (queue) { if (capped) RT_LAUNCH_M(kBvh4q, true, true); else RT_LAUNCH_M(kBvh4q, false, true); }
+            else       { if (capped) RT_LAUNCH_M(kBvh4q, true, false); else RT_LAUNCH_M(kBvh4q, false, false); }
+        } else RT_LAUNCH_M(kBvh2, false, false);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_M
         return hipGetLastError();

@@ -126,6 +126,7 @@ struct Replica {
     uint32_t* d_bin = nullptr; uint64_t bin_cap = 0;
     // spill area of the strip kernel's capped stack: kSpillSlots buffers used round-robin with the cursor sets
     int* d_spill = nullptr; uint64_t spill_cap = 0; uint32_t scratch_seq = 0;
+    uint64_t spill_words = 0;           // size of one spill set at the last launch
     // primary rays / hits of the ray-buffer primary path when the caller does not ask for them
     void* d_prim = nullptr; size_t prim_cap = 0;
     // Launches of one slot share the scratch above.  Stream order protects launches on one stream; for launches on
@@ -210,10 +211,11 @@ struct rt_ctx {
     int ray_packets = 0;        // closest-hit ray buffers walk as packets of 64 consecutive rays (RT_OPT_RAY_PACKETS)
     int sah_trav_x100 = 120;    // SAH cost of an interior step, in hundredths of a triangle test
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
-    int refill = 16 | (12 << 8); // low byte: idle lanes that trigger a refill; high: leaf-vote threshold (profiles/r02v_sweep_refill.txt)
-    int lds_stack = 20;         // ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
+    int refill = 16 | (12 << 8); // (= kDefaultRefill) low byte: idle lanes that trigger a refill; high: leaf-vote threshold (profiles/r02v_sweep_refill.txt)
+    int lds_stack = 20;         // (= kDefaultLdsStack) ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)
     int primary_path = 0;       // primary rays: 0 auto, 1 tile kernel (k_primary), 2 ray generation + ray-buffer kernel
     int binning = 2;            // ray binning before the ray-buffer kernel: 0 off, 1 on, 2 auto (structure larger than the L2s)
+    int ray_queue = 2;          // ray-buffer kernel: staged ray queue in LDS: 0 off, 1 on, 2 auto = launches that are not binned (RT_OPT_RAY_QUEUE)
     int fused_paths = 1;        // rt_render on brute-force scenes: 1 = the whole path loop in one kernel, 0 = the staged pipeline (RT_OPT_FUSED_PATHS)
     int frame_exchange = 0;     // multi-slot frames: 0 auto, 1 RCCL send/recv, 2 peer copies (RT_OPT_FRAME_EXCHANGE)
     Rccl rccl;
@@ -278,6 +280,9 @@ void free_scene(Replica& r) {
 // (launch_bin), which keeps a wave's node fetches close together when the structure does not fit the L2s.
 constexpr uint64_t kBinMinRays = 1ull << 18;
 constexpr uint64_t kBinMinSceneBytes = 48ull << 20;
+constexpr int kDefaultRefill = 16 | (12 << 8);   // RT_OPT_REFILL as rt_create leaves it
+constexpr int kDefaultLdsStack = 20;      // RT_OPT_LDS_STACK as rt_create leaves it
+constexpr int kQueueLdsStack = 12;        // stack entries per lane in LDS when the staged ray queue takes its 8 KB per block
 constexpr uint32_t kBinMinRun = 128;      // mean rays per non-empty (64 Ki-ray block, cell) pair above which a buffer counts as coherent
 bool wants_binning(const rt_ctx* c, int mode, uint64_t n) {
     const uint64_t scene_bytes = (uint64_t)c->stats.n_nodes * 64 + (uint64_t)c->stats.n_tris * 48;
@@ -315,19 +320,34 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
     }
     StripScratch sc;
     int set = -1;
+    int refill = c->refill;
     if (strip_kernel) {
         set = (int)(r.scratch_seq++ % kSpillSlots);
         sc.work = r.d_counters + kCountersPad + (size_t)set * kWorkWords;
         sc.lds_cap = c->lds_stack;
-        if (c->refill == (16 | (12 << 8))) sc.refill_perm = 32 | (8 << 8);      // the default thresholds: large permuted buffers get their own (kernels.hip launch_trace); an explicit RT_OPT_REFILL holds for all
+        // Staged ray queue (k_trace_strip<QUEUE>): refills cost a few LDS reads, so they run from 6 idle lanes on and the triangle
+        // block whenever a leaf is parked.  Pays when the structure is served by the L2s (bench frame: bounce launch -2.5 %);
+        // structures that get their rays binned lose with it (10 M-triangle soup -1 .. -7 %): profiles/r05_ray_queue.txt.
+        // The queue takes 8 KB of LDS per block; 12 stack entries in LDS instead of 20 keep 7 blocks per CU and cost nothing there.
+        sc.queue = mode == kBvh4q && n < (1ull << 32) && (c->ray_queue == 1 || (c->ray_queue == 2 && !bin));
+        if (sc.queue && sc.lds_cap == kDefaultLdsStack) sc.lds_cap = kQueueLdsStack;      // an explicit RT_OPT_LDS_STACK holds
+        if (sc.queue && c->refill == kDefaultRefill) refill = 6 | (1 << 8);
+        if (c->refill == kDefaultRefill) sc.refill_perm = 32 | (8 << 8);      // the default thresholds: large permuted buffers get their own (kernels.hip launch_trace); an explicit RT_OPT_REFILL holds for all
         // Structures that do not fit the L2s (the ones whose rays get binned), buffers below 2^25 rays: the rays in flight at
         // once are a large part of the buffer, so the region of the scene they touch outgrows the caches (10 M-triangle soup,
         // 8 Mi rays: L2 hit 52 %, HBM 5.8 TB/s -- the launch is HBM-bound; profiles/r04j_c4_8mi_summary.md).  Fewer resident
         // waves (32 stack entries in LDS: 5 blocks per CU instead of 7) shrink that region: 2 Mi rays +12 %, 4-16 Mi +3-5 %,
         // from 32 Mi on the smaller cap is ahead again (profiles/r04k_c4_cap_sweep.txt).
-        if (bin && sc.lds_cap >= 2 && n < (1ull << 25)) sc.lds_cap = std::max(sc.lds_cap, 32);
+        if (bin && !sc.queue && sc.lds_cap >= 2 && n < (1ull << 25)) sc.lds_cap = std::max(sc.lds_cap, 32);
         if (mode == kBvh4q) {
-            const uint64_t words = c->lds_stack ? spill_words(c->stack_need, c->lds_stack, device_cus()) : 0;
+            // the spill columns are sized for the smallest LDS part any launch of this context may choose
+            const int cap_lo = c->lds_stack == kDefaultLdsStack && c->ray_queue ? kQueueLdsStack : c->lds_stack;
+            const uint64_t words = cap_lo ? spill_words(c->stack_need, cap_lo, device_cus()) : 0;
+            if (words != r.spill_words && r.spill_words) {
+                // an option changed the size of a spill set: the sets of launches still running would overlap the new ones
+                if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+            }
+            r.spill_words = words;
             if (words) {
                 if (words * kSpillSlots > r.spill_cap) {
                     if (r.d_spill) (void)hipFree(r.d_spill);
@@ -341,7 +361,7 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         }
         if ((e = scratch_acquire(r, set, st)) != hipSuccess) return e;
     }
-    e = launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, c->refill, perm,
+    e = launch_trace(c->dev_scene(r), mode, any_hit, count, d_rays, n, d_hits, d_occ, r.d_counters, st, c->strip, refill, perm,
                      perm ? bin_flag(perm, n) : nullptr, sc);
     if (e != hipSuccess) return e;
     if (set >= 0 && (e = scratch_release(r, set, st)) != hipSuccess) return e;
@@ -649,6 +669,7 @@ int rt_set_option(rt_ctx* c, int key, int64_t v) try {
         case RT_OPT_SAH_BINS:    if (v < 4 || v > 32) return fail(c, RT_E_INVALID, "RT_OPT_SAH_BINS in [4,32]"); c->sah_bins = (int)v; return RT_OK;
         case RT_OPT_SAH_TRAV:    if (v < 1 || v > 10000) return fail(c, RT_E_INVALID, "RT_OPT_SAH_TRAV in [1,10000] (hundredths)"); c->sah_trav_x100 = (int)v; return RT_OK;
         case RT_OPT_RAY_PACKETS: if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PACKETS: 0 off, 1 on"); c->ray_packets = (int)v; return RT_OK;
+        case RT_OPT_RAY_QUEUE:   if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_RAY_QUEUE: 0 off, 1 on, 2 auto"); c->ray_queue = (int)v; return RT_OK;
         case RT_OPT_FUSED_PATHS: if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_FUSED_PATHS: 0 staged, 1 fused"); c->fused_paths = (int)v; return RT_OK;
         case RT_OPT_FRAME_EXCHANGE: if (v < 0 || v > 2) return fail(c, RT_E_INVALID, "RT_OPT_FRAME_EXCHANGE: 0 auto, 1 RCCL, 2 peer copies"); c->frame_exchange = (int)v; return RT_OK;
         case RT_OPT_RAY_PAD:     if (v < 0 || v > 1) return fail(c, RT_E_INVALID, "RT_OPT_RAY_PAD: 0 off, 1 on"); c->ray_pad = (int)v; return RT_OK;

@@ -469,6 +469,50 @@ def test_capped_lds_stack_with_spill_changes_nothing(renderer, torch_dev):
         renderer.set_option(rt.OPT_LDS_STACK, 1)
 
 
+def test_staged_ray_queue_changes_nothing(renderer, torch_dev):
+    """RT_OPT_RAY_QUEUE: idle lanes of the ray-buffer kernel start their next ray from a queue of prepared rays in LDS (filled by
+    half the wave) instead of loading and preparing it themselves.  Closest-hit records and any-hit flags must be the ones of the
+    kernel without the queue -- with dead rays (empty intervals) in the buffer, with spheres in the scene, with the hand-out order
+    permuted by ray binning, with the capped and the uncapped stack, for every refill threshold, and for a buffer smaller than
+    one wave."""
+    tris, sph, _ = scenes.cornell()
+    soup = scenes.soup(40000, half_extent=0.03)
+    for st, spheres, n in ((soup, None, 300007), (tris, sph, 70001), (soup, None, 37)):
+        rays = scenes.random_rays(n)
+        rays["tmax"][::13] = 0.2
+        rays["tmax"][5::17] = rays["tmin"][5::17]                     # dead rays: handed out, written as misses, never traced
+        renderer.set_option(rt.OPT_TRAVERSAL, rt.TRAVERSAL_BVH4Q)
+        renderer.create_data(st, spheres)
+        d_rays = to_dev(torch_dev, rays)
+
+        def run():
+            hits, occ = dev_buf(torch_dev, n, 16), torch_dev.zeros(n, dtype=torch_dev.uint8, device="cuda")
+            renderer.trace_dev(d_rays, n, hits)
+            renderer.occluded_dev(d_rays, n, occ)
+            torch_dev.cuda.synchronize()
+            return to_np(hits, rt.HIT).tobytes(), occ.cpu().numpy().tobytes()
+
+        renderer.set_option(rt.OPT_RAY_QUEUE, 0)
+        renderer.set_option(rt.OPT_RAY_BINNING, 0)
+        ref = run()
+        k = min(n, 1024)
+        assert_parity(np.frombuffer(ref[0], dtype=rt.HIT)[:k], oracle.trace(oracle.Scene(st, spheres), rays[:k]), "no queue vs oracle")
+        renderer.set_option(rt.OPT_RAY_QUEUE, 1)
+        for binning, cap, refill in ((0, 20, 16 | (12 << 8)), (0, 20, 1 | (0 << 8)), (0, 0, 6 | (1 << 8)), (0, 3, 64 | (64 << 8)),
+                                     (1, 20, 16 | (12 << 8)), (1, 2, 4 | (1 << 8))):
+            renderer.set_option(rt.OPT_RAY_BINNING, binning)
+            renderer.set_option(rt.OPT_LDS_STACK, cap)
+            renderer.set_option(rt.OPT_REFILL, refill)
+            assert run() == ref, f"queue on, binning {binning}, cap {cap}, refill {refill:#x}, {n} rays"
+        renderer.set_option(rt.OPT_LDS_STACK, 20)
+        renderer.set_option(rt.OPT_REFILL, 16 | (12 << 8))
+        renderer.set_option(rt.OPT_RAY_QUEUE, 2)                      # auto: on for this launch (nothing is binned at this size)
+        renderer.set_option(rt.OPT_RAY_BINNING, 2)
+        assert run() == ref, "queue auto"
+    with pytest.raises(RuntimeError):
+        renderer.set_option(rt.OPT_RAY_QUEUE, 3)
+
+
 def test_two_slots_on_one_device_equal_one_slot():
     st, rays = scenes.soup(5000, half_extent=0.05), scenes.random_rays(10001)
     tris, sph, _ = scenes.cornell()
