@@ -8,7 +8,7 @@ every stage on device, nothing skipped:
   1. k_primary      jittered primary rays generated on device + closest hit    (33.2 M rays, coherent), fused with
                     segment 0 of the path loop: emission + Cook-Torrance throughput + cosine-weighted bounce ray
                     (frag.glsl:310-350)
-  2. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent)
+  2. k_trace_strip  closest hit of the bounce rays                             (33.2 M rays, incoherent; staged ray queue)
   3. k_shade_resolve  radiance of the second (last) segment + average, gamma -> RGBA8 framebuffer (frag.glsl:357-359)
   4. N > 1 only: gather of the per-rank framebuffer stripes to rank 0 over RCCL/xGMI + de-interleave
 value = closest-hit rays of the whole job / wall time (max over ranks).  With N ranks the frame's 16-row
@@ -322,13 +322,14 @@ def main():
                   "backend": (dist.get_backend() if grouped else None),          # "nccl" = RCCL over xGMI
                   "exchange": None if not grouped else ("all_gather" if gather_all else "gather to rank 0"),
                   "exchange_overlaps_next_frame": bool(pipelined)},
-        # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints
+        # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints, and for
+        # the ray-buffer kernel the staged ray queues behind them (4 waves x 32 rays x 64 B; rt_api.cpp trace_rays)
         # (the packet form of the tile kernel keeps its stack in a register: no LDS)
         "launch": {"dynamic_lds_bytes_per_block": {"k_primary_packet": 0,
                                                    "k_primary": stats["stack_entries"] * 1024,
-                                                   "k_trace_strip": min(stats["stack_entries"], 20) * 1024},
+                                                   "k_trace_strip": min(stats["stack_entries"], 12) * 1024 + 8192},
                    "primary_kernel": primary_kernel,
-                   "stack_entries": stats["stack_entries"], "lds_stack_option": 20},
+                   "stack_entries": stats["stack_entries"], "lds_stack_entries": 12, "ray_queue_bytes_per_block": 8192},
         "roofline": roofline, "roofline_hbm": roofline_hbm,
         "kernels": {"primary_Mrays_s": round(n_real_local / ms_primary / 1e3, 1), "primary_shade_ms": round(ms_primary, 4),
                     "primary_work_per_ray": w_p, "primary_tflops": round(fl_p * n_real_local / (ms_primary * 1e-3) / 1e12, 3),

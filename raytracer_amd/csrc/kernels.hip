@@ -610,7 +610,10 @@ void k_trace_packet(DevScene s, const rt_ray* __restrict__ rays, uint64_t n, con
 #else
 #define RT_STRIP_ATTR
 #endif
-constexpr int kSecondStepLanes = 36;      // lanes on interior nodes from which a round takes a second interior step
+#ifndef RT_SECOND_STEP_LANES
+#define RT_SECOND_STEP_LANES 36
+#endif
+constexpr int kSecondStepLanes = RT_SECOND_STEP_LANES;      // lanes on interior nodes from which a round takes a second interior step
 // QUEUE: a staged ray queue per wave in LDS (behind the stacks, at int offset q_off).  Whenever it is empty the lower half of the
 // wave loads the next kQueue rays and computes their slab constants -- 32 lanes at work, whatever the wave's traversal state --
 // and an idle lane then starts its next ray with four ds_read_b128 instead of a global load + make_slab executed for a
