@@ -116,10 +116,7 @@ def main():
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if grouped:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        rd.init_group_quiet(backend, dev)        # RCCL / gloo banners go to stderr: stdout carries rank 0's JSON line only
 
     # ---- scene setup: flatten + upload to this rank's HBM (BVH replicated per GPU) -------------------
     tris, sph, lights, cam = scenes.sponza_class()
@@ -134,48 +131,77 @@ def main():
     primary_kernel = ({"1": "k_primary", "2": "ray generation + k_trace_strip", "3": "k_primary_packet"}.get(forced) or
                       ("k_primary_packet" if args.traversal == 3 else "ray generation + k_trace_strip" if stats["sah_cost"] > 250 else "k_primary"))
 
-    plan = rd.stripe_plan(H, world, rank, STRIPE)
+    # RT_BENCH_SHARE_OF=M (measurement aid, one rank): this GPU runs rank 0's share of a world of M ranks -- its stripes, its
+    # launches, the exchange of its share through a one-rank group -- with this file's own loop; the line then describes that
+    # share (`emulated_share_of`), not the job.  Source of the predicted scaling table of DESIGN.md 6.
+    share_of = int(os.environ.get("RT_BENCH_SHARE_OF", "0")) if world == 1 else 0
+    stripe_world = share_of or world
+    plan = rd.stripe_plan(H, stripe_world, rank, STRIPE)
+    xplan = plan if not share_of else rd.stripe_plan(plan.padded_rows, 1, 0, STRIPE)      # what the exchange moves
     n_local = plan.padded_rows * W * SPP                 # local ray slots (padding rows are dead rays)
     n_px = plan.padded_rows * W
     rays_per_step = W * H * SPP * 2                      # whole job: primary + bounce closest-hit rays
+    if share_of:
+        rays_per_step = plan.local_stripes * STRIPE * W * SPP * 2
     f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
-    rays, brays = f32(n_local * 8), f32(n_local * 8)
-    phits, bhits = f32(n_local * 4), f32(n_local * 4)
-    thr, rad = f32(n_local * 4), f32(n_local * 4)
-    # RGBA8 framebuffer stripes of this rank; two of them for N > 1, so that the gather of frame k can run while frame k + 1
-    # is traced into the other one
-    fbs = [torch.empty(n_px, dtype=torch.int32, device=dev) for _ in range(2 if grouped else 1)]
-    gidx = rd.gather_index(plan, dev) if grouped else None
-    state = {"k": 0, "ticket": None, "frame": None}
+    gather_all = os.environ.get("RT_BENCH_GATHER", "root") == "all"          # "all": every rank gets the frame (all-gather)
+    # RCCL, gather to rank 0: the exchange of frame k is asynchronous (RCCL's own stream) and overlaps the kernels of frame
+    # k + 1; frame k is complete on rank 0 -- waited for and de-interleaved -- by the end of step k + 1, the last one by the
+    # drain inside the timed region.  RT_BENCH_GATHER_SYNC=1 keeps the blocking form for A/B runs.
+    pipelined = grouped and backend == "nccl" and not gather_all and os.environ.get("RT_BENCH_GATHER_SYNC") != "1"
+    # Frames in flight (N >= 8 with the pipelined exchange): successive frames alternate between two streams with their own path
+    # buffers, so that the kernels of frame k + 1 fill the end of frame k's launches -- the slowest rays of a launch finish with
+    # the chip half empty, a fixed ~0.2 ms per frame that is 3 % of a whole frame but a quarter of one rank's share at N = 8.
+    # Measured with this loop on one GPU (RT_BENCH_SHARE_OF, scripts/share_bench.sh, profiles/r05l_share_bench.txt): the share of
+    # one rank of 8 takes 0.84 ms per frame with one frame in flight and 0.79-0.80 with two; shares of a half or a quarter of the
+    # frame, and the whole frame, LOSE 1-5 % with two (the launches are long against their tails, and two persistent kernels
+    # side by side take each other's cache), so fewer than 8 ranks keep one.  Two, not three: HIP maps a process's streams onto
+    # 4 hardware queues and a third stream shares its queue with the first (kernel trace: scripts/frames_trace.sh).
+    # K timed steps still deliver K complete frames on rank 0.
+    F = max(1, int(os.environ.get("RT_BENCH_FRAMES", "2" if (pipelined and stripe_world >= 8) else "1"))) if pipelined else 1
+    rays, phits = f32(n_local * 8), f32(n_local * 4)                 # unfused primary pass (instrumentation, parity sample)
+    path = [dict(brays=f32(n_local * 8), bhits=f32(n_local * 4), thr=f32(n_local * 4), rad=f32(n_local * 4)) for _ in range(F)]
+    brays, bhits = path[0]["brays"], path[0]["bhits"]
+    # RGBA8 framebuffer stripes of this rank; F + 1 of them for N > 1, so that the gather of frame k can run while the
+    # frames after it are traced into the others
+    fbs = [torch.empty(n_px, dtype=torch.int32, device=dev) for _ in range(F + 1 if grouped else 1)]
+    gidx = rd.gather_index(xplan, dev) if grouped else None
+    state = {"k": 0, "ticket": None, "frame": None, "ticket_fb": None}
     cur_fb = lambda: fbs[state["k"] % len(fbs)]
-    stream = torch.cuda.current_stream()
+    cur = lambda: path[state["k"] % F]
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] if F == 1 else [torch.cuda.Stream(device=dev) for _ in range(F)]
+    xs = main_stream if F == 1 else torch.cuda.Stream(device=dev)     # the exchange: gathers and de-interleaves, in frame order
+    cur_stream = lambda: streams[state["k"] % F]
+    fb_free = [None] * len(fbs)                                       # event: the gather that read this framebuffer is complete
     row_len = W * SPP
     key0 = plan.y0 * row_len                                         # RNG key = path index in the full frame
 
     def stage_primary_shade():
         # primary rays, their closest hits and segment 0 of the path loop in one launch: the primary rays and
         # hits stay in registers, throughput / radiance / bounce rays are written once
-        r.primary_shade_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, world, thr, rad, brays, spp=SPP, seed=SEED,
-                                    jitter=True, shade_seed=SEED + 1, stream=stream)
+        b = cur()
+        r.primary_shade_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, stripe_world, b["thr"], b["rad"], b["brays"], spp=SPP, seed=SEED,
+                                    jitter=True, shade_seed=SEED + 1, stream=cur_stream())
 
     def unfused_primary():
         # same rays and hits through the separate entry point: instrumented pass and parity sample only (untimed)
-        r.trace_primary_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, world, phits, rays, spp=SPP, seed=SEED,
-                                    jitter=True, stream=stream)
+        r.trace_primary_stripes_dev(W, H, plan.y0, plan.padded_rows, STRIPE, stripe_world, phits, rays, spp=SPP, seed=SEED,
+                                    jitter=True, stream=main_stream)
 
     def stage_bounce_trace():
-        r.trace_dev(brays, n_local, bhits, stream=stream)
+        b = cur()
+        r.trace_dev(b["brays"], n_local, b["bhits"], stream=cur_stream())
 
     def stage_shade2_resolve():
         # radiance of the second (last) segment + resolve in one launch: the final radiance stays in registers
-        r.shade_resolve_dev(brays, bhits, n_local, SPP, thr, rad, None, cur_fb(), stream=stream)
+        b = cur()
+        free = fb_free[state["k"] % len(fbs)]
+        if free is not None:                      # F > 1: the gather of the frame that used this framebuffer last must be through
+            cur_stream().wait_event(free)
+        r.shade_resolve_dev(b["brays"], b["bhits"], n_local, SPP, b["thr"], b["rad"], None, cur_fb(), stream=cur_stream())
 
-    gather_all = os.environ.get("RT_BENCH_GATHER", "root") == "all"          # "all": every rank gets the frame (all-gather)
-    # RCCL, gather to rank 0: the exchange of frame k is asynchronous (RCCL's own stream) and overlaps the kernels of frame
-    # k + 1; frame k is complete on rank 0 -- waited for and de-interleaved -- by the end of step k + 1, the last one by the
-    # drain inside the timed region.  RT_BENCH_GATHER_SYNC=1 keeps the blocking form for A/B runs.
-    pipelined = grouped and backend == "nccl" and not gather_all and os.environ.get("RT_BENCH_GATHER_SYNC") != "1"
-    fg = rd.FrameGather(plan, (W,), torch.int32, dev, 0, gidx) if pipelined else None
+    fg = rd.FrameGather(xplan, (W,), torch.int32, dev, 0, gidx) if pipelined else None
 
     def stage_gather():
         # per-rank RGBA8 stripes -> the frame on rank 0 (what shows it): each rank sends its 4 MB once, over its own
@@ -185,20 +211,30 @@ def main():
             return
         mine = cur_fb().view(plan.padded_rows, W)
         if pipelined:
-            ticket = fg.start(mine)
-            if state["ticket"] is not None:
-                state["frame"] = fg.finish(state["ticket"])
-            state["ticket"] = ticket
+            if F > 1:                             # the exchange stream takes over behind this frame's kernels
+                done = torch.cuda.Event()
+                done.record(cur_stream())
+                xs.wait_event(done)
+            with torch.cuda.stream(xs):
+                ticket = fg.start(mine)
+                if state["ticket"] is not None:
+                    state["frame"] = fg.finish(state["ticket"])
+                    if F > 1:
+                        ev = torch.cuda.Event(); ev.record(xs); fb_free[state["ticket_fb"]] = ev
+            state["ticket"], state["ticket_fb"] = ticket, state["k"] % len(fbs)
             return
         if backend != "nccl":                                                    # rehearsal: stage through the host
             mine, idx = mine.cpu(), gidx.cpu()
         else:
             idx = gidx
-        state["frame"] = rd.gather_rows(mine, plan, idx) if gather_all else rd.gather_rows_to(mine, plan, 0, idx)
+        state["frame"] = rd.gather_rows(mine, xplan, idx) if gather_all else rd.gather_rows_to(mine, xplan, 0, idx)
 
     def drain():
         if state["ticket"] is not None:
-            state["frame"] = fg.finish(state["ticket"])
+            with torch.cuda.stream(xs):
+                state["frame"] = fg.finish(state["ticket"])
+                if F > 1:
+                    ev = torch.cuda.Event(); ev.record(xs); fb_free[state["ticket_fb"]] = ev
             state["ticket"] = None
 
     stages = [stage_primary_shade, stage_bounce_trace, stage_shade2_resolve, stage_gather]
@@ -222,17 +258,34 @@ def main():
         step()
     drain()
     ne = len(stages) + 1
+    probe = None
+    if F > 1:
+        # per-stage times of single launches: three frames run one at a time, before the timed region (in it the stages of
+        # neighbouring frames overlap, which is the point of F > 1, and events around one stage would time its neighbours too)
+        probe = [[torch.cuda.Event(enable_timing=True) for _ in range(ne)] for _ in range(3)]
+        for pe in probe:
+            torch.cuda.synchronize()
+            pe[0].record(cur_stream())
+            for j, st in enumerate(stages):
+                st_stream = cur_stream()
+                st()
+                pe[j + 1].record(st_stream)
+            state["k"] += 1
+            drain()
+        torch.cuda.synchronize()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(ne)] for _ in range(args.steps)]
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
+        st_stream = cur_stream()
+        ev[k][0].record(st_stream)
         for j, st in enumerate(stages):
             st()
-            ev[k][j + 1].record(stream)
+            ev[k][j + 1].record(st_stream)
         state["k"] += 1
+    t_enqueued = time.perf_counter() - t0                # host time to queue the K steps (the GPU runs behind it)
     drain()                                              # the last frame's gather + de-interleave belong to the K steps
     if grouped:
         dist.barrier()
@@ -243,7 +296,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms = [float(np.mean([ev[k][j].elapsed_time(ev[k][j + 1]) for k in range(args.steps)])) for j in range(len(stages))]
+    tev = probe if probe is not None else ev
+    ms = [float(np.mean([e[j].elapsed_time(e[j + 1]) for e in tev])) for j in range(len(stages))]
     ms_primary, ms_btrace, ms_shade2, ms_gather = ms
 
     step()                                               # one more (untimed) frame for the checksum below
@@ -255,7 +309,7 @@ def main():
         if grouped:
             dist.destroy_process_group()
         return
-    frame_np = frame.reshape(-1)[: W * H].cpu().numpy()
+    frame_np = frame.reshape(-1)[: W * (xplan.h if share_of else H)].cpu().numpy()
     frame_sha = hashlib.sha256(frame_np.tobytes()).hexdigest()
     lit_pixels = int((frame_np.view("uint32") & 0xFFFFFF != 0).sum())       # the hash says something only if the frame is not black
 
@@ -308,11 +362,13 @@ def main():
     out = {
         "metric": "closest-hit Mrays/s", "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3 sponza-class stand-in (8x8 sphereGeometry(45,45) in a room, 259212 tris), "
                                "3840x2160 x 4 spp jittered primary + 1 cosine-weighted bounce, closest-hit + shading "
                                "to an RGBA8 framebuffer",
-                   "rays_per_step": rays_per_step, "parallelism": f"stripes{STRIPE}x{world}",
+                   "rays_per_step": rays_per_step, "parallelism": f"stripes{STRIPE}x{stripe_world}",
+                   **({"emulated_share_of": share_of} if share_of else {}),
                    "bvh": {"layout": "bvh4q" if args.traversal == 3 else "bvh2", "nodes": stats["n_nodes"],
                            "depth": stats["max_depth"], "node_bytes": stats["node_bytes"],
                            "tri_bytes": stats["tri_bytes"], "build_ms": round(stats["build_ms"], 1)}},
@@ -321,7 +377,10 @@ def main():
         "ranks": {"world_size": dist.get_world_size() if grouped else 1,
                   "backend": (dist.get_backend() if grouped else None),          # "nccl" = RCCL over xGMI
                   "exchange": None if not grouped else ("all_gather" if gather_all else "gather to rank 0"),
-                  "exchange_overlaps_next_frame": bool(pipelined)},
+                  "exchange_overlaps_next_frame": bool(pipelined),
+                  # F > 1: the kernels of successive frames overlap on F streams; the per-stage times below then come from three
+                  # frames run one at a time before the timed region
+                  "frames_in_flight": F, "stage_times_from": "timed region" if probe is None else "3 single frames before the timed region"},
         # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints, and for
         # the ray-buffer kernel the staged ray queues behind them (4 waves x 32 rays x 64 B; rt_api.cpp trace_rays)
         # (the packet form of the tile kernel keeps its stack in a register: no LDS)

@@ -157,6 +157,29 @@ class FrameGather:
         return full.index_select(0, self.index)
 
 
+def init_group_quiet(backend, device=None):
+    """init_process_group + a first barrier with file descriptor 1 pointing at stderr meanwhile: RCCL and gloo announce
+    themselves on STDOUT when their communicators come up ("RCCL version : ...", "[Gloo] Rank 0 is connected to ..."), and the
+    launch scripts keep stdout for rank 0's one JSON line."""
+    import os
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        dist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def shard_range(n, world, rank):
     """Contiguous range [first, first+count) of rank; every rank's padded count is ceil(n/world)."""
     per = (n + world - 1) // world

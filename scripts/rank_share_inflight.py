@@ -1,5 +1,5 @@
 """rank_share_probe.py with F frames in flight: frame k runs on stream k % F with its own buffers, so the tail of one
-frame's launches is filled by the next frame's.  Prints ms per frame (throughput) for rank 0 of N, F = 1, 2, 3."""
+frame's launches is filled by the next frame's.  Prints ms per frame (throughput) for rank 0 of N, F = 1, 2, 3, 4, 6."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ r = rt.Renderer((0,)); r.create_data(tris, sph, lights); r.update_camera(cam)
 for world in (1, 2, 4, 8):
     plan = rd.stripe_plan(H, world, 0, STRIPE)
     n = plan.padded_rows * W * SPP
-    for F in (1, 2, 3):
+    for F in (1, 2, 3, 4, 6):
         f = lambda k: torch.empty(n * k, dtype=torch.float32, device="cuda")
         sets = [dict(thr=f(4), rad=f(4), brays=f(8), bhits=f(4), fb=torch.empty(plan.padded_rows * W, dtype=torch.int32, device="cuda"),
                      st=torch.cuda.Stream()) for _ in range(F)]

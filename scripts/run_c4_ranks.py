@@ -37,7 +37,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        rd.init_group_quiet(backend, dev)
     tris = scenes.soup(a.soup)
     first, count, per = rd.shard_range(a.rays, world, rank)
     rays_np = np.zeros(per, dtype=rt.RAY)                                  # padded to `per`: dead rays (tmax 0) past the end

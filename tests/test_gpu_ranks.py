@@ -27,8 +27,8 @@ def _run(cmd, extra_env, timeout=420):
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, f"{cmd}: rc {p.returncode}\n{p.stderr[-3000:]}"
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, f"rank 0 prints exactly one JSON line, got {len(lines)}:\n{p.stdout[-2000:]}"
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"stdout carries exactly one line, rank 0's JSON; got {len(lines)}:\n{p.stdout[-2000:]}"
     return json.loads(lines[0])
 
 
@@ -52,16 +52,26 @@ def test_bench_two_ranks_self_launched_give_the_single_rank_frame():
 def test_bench_exchange_code_on_rccl_with_one_rank():
     """RT_BENCH_FORCE_GROUP=1: bench.py with a one-rank "nccl" (= RCCL) process group on the GPU -- the pipelined exchange exactly as N
     ranks run it (asynchronous gather of frame k into alternating buffers while frame k + 1 is traced, drain, barrier, max over
-    ranks) -- and the blocking and all-gather forms: same frame as the plain run."""
-    base = [sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    ranks) -- with one frame in flight and with three (RT_BENCH_FRAMES=3: what N > 1 ranks run by default -- successive frames
+    on three streams with their own path buffers, the exchange on a stream of its own, framebuffers released by events), and the
+    blocking and all-gather forms: same frame as the plain run."""
+    base = [sys.executable, "bench.py", "--steps", "7", "--warmup", "2", "--no-cpu-baseline"]
     one = _run(base, {})
-    for extra, overlapped, exchange in (({}, True, "gather to rank 0"), ({"RT_BENCH_GATHER_SYNC": "1"}, False, "gather to rank 0"),
-                                        ({"RT_BENCH_GATHER": "all"}, False, "all_gather")):
+    assert one["ranks"]["frames_in_flight"] == 1 and one["ranks"]["stage_times_from"] == "timed region"
+    for extra, overlapped, exchange, frames in (({}, True, "gather to rank 0", 1), ({"RT_BENCH_FRAMES": "3"}, True, "gather to rank 0", 3),
+                                                ({"RT_BENCH_FRAMES": "2"}, True, "gather to rank 0", 2),
+                                                ({"RT_BENCH_GATHER_SYNC": "1", "RT_BENCH_FRAMES": "3"}, False, "gather to rank 0", 1),
+                                                ({"RT_BENCH_GATHER": "all"}, False, "all_gather", 1)):
         got = _run(base, dict(extra, RT_BENCH_FORCE_GROUP="1"))
         assert got["ranks"]["backend"] == "nccl" and got["ranks"]["world_size"] == 1
         assert got["ranks"]["exchange"] == exchange and got["ranks"]["exchange_overlaps_next_frame"] is overlapped
+        assert got["ranks"]["frames_in_flight"] == frames
         assert got["frame_sha256"] == one["frame_sha256"], extra
         assert got["ms_per_step"] < 3 * one["ms_per_step"]
+        if frames > 1:                              # stage times of single launches, taken before the timed region
+            assert got["ranks"]["stage_times_from"].startswith("3 single frames")
+            k, k1 = got["kernels"], one["kernels"]
+            assert abs(k["bounce_ms"] - k1["bounce_ms"]) < 0.15 * k1["bounce_ms"], (k, k1)
 
 
 def test_c4_ray_ranges_over_two_and_three_ranks_give_the_single_rank_hits():
