@@ -691,8 +691,8 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                 // published once in a mask word on its own line and later waves skip them after one plain load.
                 uint32_t mask = 0;
                 if ((threadIdx.x & 63) == 0) {
-                    mask = (uint32_t)__hip_atomic_load(&work[kWorkMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(mask & (1u << q))) atomicOr(&work[kWorkMask], 1ull << q);
+                    mask = (uint32_t)__hip_atomic_load(&work[8 * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(mask & (1u << q))) atomicOr(&work[8 * kCursorStride], 1ull << q);
                 }
                 q_done |= __builtin_amdgcn_readfirstlane(mask) | (1u << q);
                 const uint32_t cand = ~q_done & 0xffu;
@@ -847,16 +847,6 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             const uint64_t at = QUEUE ? (uint64_t)my32 : my;
             if (ANY) occ[at] = b.t < tmax ? 1 : 0;
             else     hits[at] = pack_hit(b, tmax);
-        }
-    }
-    // The last wave out leaves the cursor set as it found it -- zero -- for the next launch that takes this set: every other wave
-    // has made its last draw before it counted itself here, so nobody reads the words again.  (A memset in front of every launch
-    // cost a fill kernel and two gaps on the stream: ~11 us, 4 % of a 1.2 M-ray shadow launch.)
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned long long waves = (unsigned long long)gridDim.x * (kBlock / 64);
-        if (atomicAdd(&work[kWorkDone], 1ull) == waves - 1ull) {
-            #pragma unroll
-            for (int k = 0; k < 10; ++k) __hip_atomic_store(&work[k * kCursorStride], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (COUNT) {
@@ -1786,9 +1776,11 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
     const int rf_perm = (d_perm && sc.refill_perm && n >= (1ull << 25)) ? sc.refill_perm : 0;
     if (mode != kBrute && strip >= 64) {
         // strip kernel: persistent waves, as many blocks as the chip holds at once (LDS-limited), never more than
-        // there are chunks.  The chunk cursors live in the caller's scratch (sc.work).
+        // there are chunks.  The chunk cursors live in the caller's scratch (sc.work), zeroed on the stream.
         if (!sc.work) return hipErrorInvalidValue;
-        unsigned long long* work = sc.work;        // zero: rt_create cleared it, and every launch leaves it cleared (k_trace_strip's last wave)
+        unsigned long long* work = sc.work;
+        hipError_t e = hipMemsetAsync(work, 0, kWorkWords * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
         // chunk size: the option is the maximum; smaller buffers get smaller chunks (down to one wave's worth), so that
         // a full grid still draws >= 8 chunks per wave and the launch does not end in a long tail of half-empty waves
         {

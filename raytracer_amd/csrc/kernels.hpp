@@ -56,9 +56,7 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
                       uint32_t max_blocks = kBinBlocksMax, bool two_level = false);
 
 // Scratch of one strip-kernel launch (the caller owns it and keeps launches that share it ordered):
-//   work       kWorkWords u64: 8 chunk cursors, the mask of exhausted eighths and a count of finished waves, kCursorStride apart.
-//              Zero when the caller hands it over for the first time; every launch leaves it zero again (its last wave out
-//              clears it), so launches need no memset of their own
+//   work       kWorkWords u64: 8 chunk cursors + the mask of exhausted eighths, kCursorStride apart (zeroed by launch_trace)
 //   spill      BVH4q: spill_words() ints, enables the capped LDS stack (null = whole stack in LDS)
 //   lds_cap    stack entries per lane kept in LDS when spill is given
 //   max_blocks bound on the persistent grid (0 = none): the spill area holds one column per thread of the grid
@@ -135,8 +133,7 @@ hipError_t launch_gather_rows(const uint32_t* stage, uint32_t* frame, uint32_t h
 constexpr int kStackDepth = 32;   // BVH2 depth budget + 2: bounds the per-lane traversal stack of the BVH2 layout
 constexpr int kWorkSlots = 4;     // chunk-cursor sets behind the counters: one per scratch slot of a replica (rt_api.cpp)
 constexpr int kCursorStride = 16;       // u64 words between chunk cursors: one 128-B line each, so they sit in different L2 channels
-constexpr int kWorkWords = 10 * kCursorStride;  // 8 cursors + the mask of exhausted eighths + the count of waves that are through
-constexpr int kWorkMask = 8 * kCursorStride, kWorkDone = 9 * kCursorStride;
+constexpr int kWorkWords = 9 * kCursorStride;   // 8 cursors + the mask of exhausted eighths
 constexpr int kCountersPad = 16;        // the counters take the first line of the buffer, the cursor sets follow
 constexpr int kNumCounters = 12;  // rays, box_tests, nodes, tri_tests, sphere_tests, sum wave-max nodes, sum wave-max tris, waves, + 4 strip-kernel scheduling probes
 
