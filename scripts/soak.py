@@ -34,9 +34,9 @@ with rt.Renderer((0,)) as r:
     hits = torch.empty(n4 * 4, dtype=torch.float32, device=dev); occ = torch.empty(n4, dtype=torch.uint8, device=dev)
     ref, bad = None, 0
     for it in range(60):
-        r.set_option(rt.OPT_RAY_BINNING, (2, 1, 0)[it % 3]); r.set_option(rt.OPT_LDS_STACK, (20, 4, 0, 12)[it % 4])
+        r.set_option(rt.OPT_RAY_BINNING, (2, 1, 0)[it % 3]); r.set_option(rt.OPT_LDS_STACK, (20, 4, 0, 12)[it % 4]); r.set_option(rt.OPT_RAY_QUEUE, (2, 1, 0, 1, 2)[it % 5])
         r.trace_dev(rays, n4, hits); r.occluded_dev(rays, n4, occ); torch.cuda.synchronize()
         cur = (hits.clone(), occ.clone())
         if ref is None: ref = cur
         elif not (torch.equal(cur[0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(cur[1], ref[1])): bad += 1
-    print(f"soup 3M x 16Mi rays x60 (binning / stack cap cycled): {bad} differing results", flush=True)
+    print(f"soup 3M x 16Mi rays x60 (binning / stack cap / ray queue cycled): {bad} differing results", flush=True)
