@@ -668,6 +668,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
 #endif
     for (;;) {
         const bool idle = node == kDone && pend == 0;
+        bool fresh = false;                                          // QUEUE: this lane took a ray from the queue in this round
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
         if (cur >= lim && more && (QUEUE ? q_avail == 0u : n_idle >= refill)) {
@@ -721,26 +722,22 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             }
             if (q_avail != 0u && n_idle >= refill) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-                if (idle && rank < q_avail) {
+                fresh = idle && rank < q_avail;
+                if (fresh) {
                     const float4* qe = qw + (q_head + rank);
                     const float4 r0 = qe[0], r1 = qe[kQueue], a = qe[2 * kQueue], e = qe[3 * kQueue];
                     o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
                     my32 = __float_as_uint(e.w);
                     tmin0 = fmaxf(tmin, 0.0f);
                     b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
-                    bool go = tmax > tmin;
-                    if (COUNT && go) ++n_mine;
-                    if (go) {
-                        spheres_pass<COUNT>(s, o, d, tmin, b, c);
-                        go = !(ANY && b.t < tmax) && s.n_nodes != 0;
-                    }
-                    if (go) {
-                        sl.ix = a.x; sl.iy = a.y; sl.iz = a.z; sl.m2 = a.w; sl.ex = e.x; sl.ey = e.y; sl.ez = e.z;
-                        node = 0; sp = 1;
-                    } else {
-                        if (ANY) occ[my32] = b.t < tmax ? 1 : 0;
-                        else     hits[my32] = pack_hit(b, tmax);
-                    }
+                    sl.ix = a.x; sl.iy = a.y; sl.iz = a.z; sl.m2 = a.w; sl.ex = e.x; sl.ey = e.y; sl.ez = e.z;
+                    if (COUNT && tmax > tmin) ++n_mine;
+                    // (spheres against an empty interval accept nothing: consider() wants tmin <= t < tmax)
+                    if (s.n_spheres) spheres_pass<COUNT>(s, o, d, tmin, b, c);
+                    // A ray with an empty interval, a sphere hit that settles an any-hit query, a scene without triangles: the
+                    // lane is through at once and the write at the end of this round records it (`fresh` keeps it live until then).
+                    const bool go = tmax > tmin && !(ANY && b.t < tmax) && s.n_nodes != 0;
+                    node = go ? 0 : kDone; sp = 1;
                 }
                 const uint32_t took = (uint32_t)n_idle < q_avail ? (uint32_t)n_idle : q_avail;
                 q_head += took; q_avail -= took;
@@ -772,7 +769,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
             }
             cur += (uint32_t)n_idle;
         }
-        const bool live = !(node == kDone && pend == 0);
+        const bool live = !(node == kDone && pend == 0) || (QUEUE && fresh);
         if (__ballot(live) == 0ull) {
             if (cur >= lim && !more && q_avail == 0u) break;
             continue;
