@@ -668,7 +668,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
 #endif
     for (;;) {
         const bool idle = node == kDone && pend == 0;
-        bool fresh = false;                                          // QUEUE: this lane took a ray from the queue in this round
+        bool fresh = false;                                          // this lane started a ray in this round
         const unsigned long long im = __ballot(idle);
         const int n_idle = __popcll(im);
         if (cur >= lim && more && (QUEUE ? q_avail == 0u : n_idle >= refill)) {
@@ -732,8 +732,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                     b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
                     sl.ix = a.x; sl.iy = a.y; sl.iz = a.z; sl.m2 = a.w; sl.ex = e.x; sl.ey = e.y; sl.ez = e.z;
                     if (COUNT && tmax > tmin) ++n_mine;
-                    // (spheres against an empty interval accept nothing: consider() wants tmin <= t < tmax)
-                    if (s.n_spheres) spheres_pass<COUNT>(s, o, d, tmin, b, c);
+                    if (s.n_spheres && tmax > tmin) spheres_pass<COUNT>(s, o, d, tmin, b, c);
                     // A ray with an empty interval, a sphere hit that settles an any-hit query, a scene without triangles: the
                     // lane is through at once and the write at the end of this round records it (`fresh` keeps it live until then).
                     const bool go = tmax > tmin && !(ANY && b.t < tmax) && s.n_nodes != 0;
@@ -745,7 +744,8 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         } else
         if (cur < lim && n_idle >= refill) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-            if (idle && cur + rank < lim) {
+            fresh = idle && cur + rank < lim;
+            if (fresh) {
                 const uint64_t cand = (uint64_t)chunk * strip + cur + rank;
                 my = perm ? (uint64_t)perm[cand] : cand;
                 const float4* rp = reinterpret_cast<const float4*>(rays + my);
@@ -753,27 +753,21 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                 o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
                 tmin0 = fmaxf(tmin, 0.0f);
                 b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
-                bool go = tmax > tmin;
-                if (COUNT && go) ++n_mine;                  // counters.rays = LIVE rays (dead slots are handed out too)
-                if (go) {
-                    spheres_pass<COUNT>(s, o, d, tmin, b, c);
-                    go = !(ANY && b.t < tmax) && s.n_nodes != 0;
-                }
-                if (go) {
-                    sl = make_slab<MODE>(o, d, s.ray_pad);
-                    node = 0; sp = 1;
-                } else {
-                    if (ANY) occ[my] = b.t < tmax ? 1 : 0;
-                    else     hits[my] = pack_hit(b, tmax);
-                }
+                if (COUNT && tmax > tmin) ++n_mine;             // counters.rays = LIVE rays (dead slots are handed out too)
+                if (s.n_spheres && tmax > tmin) spheres_pass<COUNT>(s, o, d, tmin, b, c);
+                sl = make_slab<MODE>(o, d, s.ray_pad);
+                // empty interval, settled any-hit query, no triangles: through at once; the write at the end of this round
+                // records the lane (`fresh` keeps it live until then)
+                const bool go = tmax > tmin && !(ANY && b.t < tmax) && s.n_nodes != 0;
+                node = go ? 0 : kDone; sp = 1;
             }
             cur += (uint32_t)n_idle;
         }
-        const bool live = !(node == kDone && pend == 0) || (QUEUE && fresh);
-        if (__ballot(live) == 0ull) {
-            if (cur >= lim && !more && q_avail == 0u) break;
-            continue;
-        }
+        const bool live = !(node == kDone && pend == 0) || fresh;
+        // One exit and no `continue`: a round in which no lane is live (between chunks, at the very end) falls through the body,
+        // where every block is skipped by its own vote.  With a `continue` here the compiler kept two copies of every value that
+        // is carried round the loop (33 more v_mov in the kernel, a dozen of them per round: bounce 3.42 -> 3.39 ms).
+        if (__ballot(live) == 0ull && cur >= lim && !more && q_avail == 0u) break;
         // if-if scheduling with one postponed leaf per lane: per round every lane does at most ONE interior
         // step and ONE triangle test, so no lane waits for the slowest lane's whole descent.  A lane that
         // reaches a leaf parks it in `pend` and keeps walking from its stack; the triangle block is skipped
