@@ -101,3 +101,29 @@ def _worker(rank, world, port, h, w, sh, n):
 @pytest.mark.parametrize("h,w,sh,n", [(37, 5, 8, 101), (64, 8, 16, 64)])
 def test_gather_world2_gloo(h, w, sh, n):
     mp.spawn(_worker, args=(2, _free_port(), h, w, sh, n), nprocs=2, join=True)
+
+
+def test_init_group_quiet_keeps_stdout_for_the_result_line(tmp_path):
+    """dist.init_group_quiet: the backends' start-up banners ("[Gloo] Rank 0 is connected to ...", RCCL's version block) go to
+    stderr, so that stdout carries rank 0's one JSON line and nothing else -- what bench.py and scripts/run_c4_ranks.py rely on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "quiet.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from raytracer_amd import dist as rd\n"
+        "rd.init_group_quiet('gloo')\n"
+        "t = torch.ones(1) * (dist.get_rank() + 1)\n"
+        "dist.all_reduce(t)\n"
+        "if dist.get_rank() == 0:\n"
+        "    print('{\"sum\": %d}' % int(t.item()), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert lines == ['{"sum": 3}'], p.stdout
