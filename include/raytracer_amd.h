@@ -79,7 +79,8 @@ enum {
                                soup-like scenes whose neighbouring rays walk unrelated paths, else 1.
                                Same rays, hits and path state in every case. */
     RT_OPT_SAH_BINS = 12,   /* BVH builder: SAH bins per axis, 4..32 (default 16); takes effect at upload.  Results are unaffected. */
-    RT_OPT_SAH_TRAV = 13,   /* BVH builder: SAH cost of one interior step in hundredths of a triangle test (default 120) */
+    RT_OPT_SAH_TRAV = 13,   /* BVH builder: SAH cost of one interior step in hundredths of a triangle test (default 60:
+                               the BVH4q step costs about as much as a triangle test, and half the children of a node are culled) */
     RT_OPT_RAY_PACKETS = 15,/* rt_trace_dev / rt_trace (closest hit) and rt_shadow_dev, BVH4q trees: 1 = every 64 consecutive rays of
                                the buffer walk the tree together as one packet, like the primary rays of the tile kernel.  Same hit records for any
                                buffer; faster only when consecutive rays really travel together (same region, similar
@@ -112,7 +113,8 @@ typedef struct {
     uint32_t max_depth;
     uint32_t node_bytes;       /* bytes per node in HBM */
     uint32_t tri_bytes;        /* bytes per intersection triangle in HBM */
-    float    sah_cost;
+    float    sah_cost;         /* SAH cost of the binary tree: 1.2 per interior step + 1 per triangle test, area-weighted (fixed weights,
+                                  independent of RT_OPT_SAH_TRAV) */
     float    build_ms;         /* host BVH build + flatten */
     float    upload_ms;        /* H2D copies */
     uint64_t device_bytes;     /* per replica */

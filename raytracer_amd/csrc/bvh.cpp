@@ -188,12 +188,16 @@ struct Builder {
         n.count = end - begin;
         if (n.count > 8) oversize_leaf.store(true, std::memory_order_relaxed);
     }
+    static constexpr float kStatTrav = 1.2f;
     Stats leaf_stats(const BuildNode& n) const {
         Stats s; s.cost = (double)P.cost_isect * n.count * n.box.half_area(); s.leaves = 1; return s;       // scaled by 1 / root area at the end
     }
     static Stats join_stats(const BuildParams& P, const BuildNode& n, const Stats& l, const Stats& r) {
         Stats s;
-        s.cost = (double)P.cost_trav * n.box.half_area() + l.cost + r.cost;
+        // the REPORTED cost always weighs an interior step as kStatTrav triangle tests, whatever the build was steered by: the
+        // figure classifies trees (rt_scene_stats.sah_cost, the primary-path rule for BVH2 trees) and must not move with a tuning option
+        (void)P;
+        s.cost = (double)kStatTrav * n.box.half_area() + l.cost + r.cost;
         s.height = 1 + std::max(l.height, r.height);
         s.leaves = l.leaves + r.leaves;
         return s;

@@ -54,7 +54,7 @@ private:
 struct BuildParams {
     int   max_leaf = 4;       // primitives per leaf (<= 8: leaf references carry a 3-bit count)
     int   max_depth = 30;     // leaves sit at depth <= max_depth (root = 0); bounds the traversal stack
-    float cost_trav = 1.2f;   // SAH: one interior step
+    float cost_trav = 0.6f;   // SAH: one interior step
     float cost_isect = 1.0f;  // SAH: one triangle test
     int   threads = 0;        // 0 = hardware concurrency, capped at 16
     int   bins = 16;          // SAH bins per axis (4..32)

@@ -209,7 +209,7 @@ struct rt_ctx {
     int max_leaf = 4;
     int sah_bins = 16;          // SAH bins per axis of the builder
     int ray_packets = 0;        // closest-hit ray buffers walk as packets of 64 consecutive rays (RT_OPT_RAY_PACKETS)
-    int sah_trav_x100 = 120;    // SAH cost of an interior step, in hundredths of a triangle test
+    int sah_trav_x100 = 60;     // SAH cost of an interior step, in hundredths of a triangle test (profiles/r05w_sah_trav.txt)
     uint32_t strip = 256;       // rays per chunk drawn by a wave of the ray-buffer kernel (0 = plain one-ray-per-lane kernel)
     int refill = 16 | (12 << 8); // (= kDefaultRefill) low byte: idle lanes that trigger a refill; high: leaf-vote threshold (profiles/r02v_sweep_refill.txt)
     int lds_stack = 20;         // (= kDefaultLdsStack) ray-buffer kernel, BVH4q: stack entries per lane kept in LDS, deeper ones spill to HBM (0 = all in LDS)

@@ -35,7 +35,7 @@ struct HostSceneParams {
     int threads = 0;
     int max_depth = 30;
     int bins = 16;           // SAH bins per axis
-    float cost_trav = 1.2f;  // SAH cost of one interior step relative to one triangle test
+    float cost_trav = 0.6f;  // SAH cost of one interior step relative to one triangle test
     bool wide = false;       // also flatten the fp32 "wide" copy of a BVH4q tree (packet traversal of the tile kernel)
     bool records = true;     // false: nodes + triangle order only (rt_bvh_build_host)
 };
