@@ -326,19 +326,23 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         sc.work = r.d_counters + kCountersPad + (size_t)set * kWorkWords;
         sc.lds_cap = c->lds_stack;
         // Staged ray queue (k_trace_strip<QUEUE>): refills cost a few LDS reads, so they run from 6 idle lanes on and the triangle
-        // block whenever a leaf is parked.  Pays when the structure is served by the L2s (bench frame: bounce launch -2.5 %);
-        // structures that get their rays binned lose with it (10 M-triangle soup -1 .. -7 %): profiles/r05_ray_queue.txt.
-        // The queue takes 8 KB of LDS per block; 12 stack entries in LDS instead of 20 keep 7 blocks per CU and cost nothing there.
-        sc.queue = mode == kBvh4q && n < (1ull << 32) && (c->ray_queue == 1 || (c->ray_queue == 2 && !bin));
-        if (sc.queue && sc.lds_cap == kDefaultLdsStack) sc.lds_cap = kQueueLdsStack;      // an explicit RT_OPT_LDS_STACK holds
+        // block whenever a leaf is parked.  Pays when the structure is served by the L2s (bench frame: bounce launch -3 %) and
+        // for binned launches below 2^25 rays (10 M-triangle soup: 2 Mi rays +8 %, 8 Mi +4 %, 16 Mi +3 %); from 2^25 rays on a
+        // binned launch loses with it (-1 .. -7 %): profiles/r05_ray_queue.txt, r05y_c4_cap.txt.
+        // The queue takes 8 KB of LDS per block.  Structures in the L2s: 12 stack entries in LDS instead of 20 cost nothing there
+        // and keep 7 blocks per CU.  Binned launches below 2^25 rays want FEWER resident waves anyway: the rays in flight at
+        // once are a large part of the buffer, so the region of the scene they touch outgrows the caches (10 M-triangle soup,
+        // 8 Mi rays, round 2's tree: L2 hit 52 %, HBM 5.8 TB/s; profiles/r04j_c4_8mi_summary.md) -- 32 entries in LDS, 4 blocks
+        // per CU with the queue (r05y_c4_cap.txt; 2 Mi rays +12 %, 4-16 Mi +3-5 % before the queue, r04k_c4_cap_sweep.txt).
+        // Explicit RT_OPT_LDS_STACK / RT_OPT_REFILL values hold.
+        const bool small_binned = bin && n < (1ull << 25);
+        sc.queue = mode == kBvh4q && n < (1ull << 32) && (c->ray_queue == 1 || (c->ray_queue == 2 && (!bin || small_binned)));
+        if (c->lds_stack == kDefaultLdsStack) {
+            if (small_binned) sc.lds_cap = 32;
+            else if (sc.queue) sc.lds_cap = kQueueLdsStack;
+        }
         if (sc.queue && c->refill == kDefaultRefill) refill = 6 | (1 << 8);
         if (c->refill == kDefaultRefill) sc.refill_perm = 32 | (8 << 8);      // the default thresholds: large permuted buffers get their own (kernels.hip launch_trace); an explicit RT_OPT_REFILL holds for all
-        // Structures that do not fit the L2s (the ones whose rays get binned), buffers below 2^25 rays: the rays in flight at
-        // once are a large part of the buffer, so the region of the scene they touch outgrows the caches (10 M-triangle soup,
-        // 8 Mi rays: L2 hit 52 %, HBM 5.8 TB/s -- the launch is HBM-bound; profiles/r04j_c4_8mi_summary.md).  Fewer resident
-        // waves (32 stack entries in LDS: 5 blocks per CU instead of 7) shrink that region: 2 Mi rays +12 %, 4-16 Mi +3-5 %,
-        // from 32 Mi on the smaller cap is ahead again (profiles/r04k_c4_cap_sweep.txt).
-        if (bin && !sc.queue && sc.lds_cap >= 2 && n < (1ull << 25)) sc.lds_cap = std::max(sc.lds_cap, 32);
         if (mode == kBvh4q) {
             // the spill columns are sized for the smallest LDS part any launch of this context may choose
             const int cap_lo = c->lds_stack == kDefaultLdsStack && c->ray_queue ? kQueueLdsStack : c->lds_stack;
