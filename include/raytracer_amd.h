@@ -66,7 +66,9 @@ enum {
                                scratch (4 B per ray): calls on one slot that bin must be stream-ordered. */
     RT_OPT_LDS_STACK = 9,   /* ray-buffer kernel, BVH4q nodes: traversal-stack entries per lane kept in LDS (default 20, 2..64);
                                deeper entries spill to a per-slot area in HBM, which lets 8 waves per SIMD run instead of
-                               3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected. */
+                               3-4.  0 = size LDS for the tree's worst case, no spill.  Results are unaffected.  Left at 20 the
+                               library picks per launch (12 beside the ray queue on structures the L2s serve, 32 for binned
+                               launches below 2^25 rays); any other value holds for every launch. */
     RT_OPT_PRIMARY = 10,    /* primary rays.  1 = tile kernel, one ray per lane with its own traversal stack (generation fused
                                with traversal and, in rt_primary_shade_stripes_dev, with the first shading segment);
                                3 = the same kernel with PACKET traversal: the 64 rays of a wave (a 4x4 .. 8x8 pixel tile)
@@ -96,10 +98,10 @@ enum {
                                0 auto (default) = 1 when all ordinals differ and RCCL loads, else 2.  Same frame in every case. */
     RT_OPT_RAY_QUEUE = 19,  /* ray-buffer kernel, BVH4q nodes: 1 = every wave keeps a queue of 32 prepared rays (origin, direction, interval,
                                slab constants, index) in LDS, filled by half the wave at once; idle lanes start their next ray from it
-                               (refills from 6 idle lanes on instead of 16, and 12 instead of 20 stack entries in LDS, unless
-                               RT_OPT_REFILL / RT_OPT_LDS_STACK say otherwise).  0 = idle lanes load and prepare their next ray
-                               themselves.  2 auto (default) = 1 for launches whose rays are not binned (structures the L2s serve),
-                               else 0.  Results are unaffected. */
+                               (refills from 6 idle lanes on instead of 16, unless RT_OPT_REFILL says otherwise).  0 = idle lanes
+                               load and prepare their next ray themselves.  2 auto (default) = 1 for launches whose rays are not
+                               binned (structures the L2s serve) and for binned launches below 2^25 rays, else 0.
+                               Results are unaffected. */
     RT_OPT_RAY_PAD = 11     /* 1 (default): the per-ray box pad described at RT_OPT_PAD_LOG2.  0 switches it off -- for
                                measuring what it protects against only: rays that start hundreds of scene extents away
                                then lose hits the reference loop finds (tests/test_gpu_parity.py, far-origin test). */
