@@ -7,7 +7,7 @@ import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
 FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize --offload-arch=gfx950".split()
-KERNEL = "_ZN2rt12_GLOBAL__N_113k_trace_stripILi3ELb0ELb0ELb1EEE"
+KERNEL = "_ZN2rt12_GLOBAL__N_113k_trace_stripILi3ELb0ELb0ELb1ELb1EEE"     # <bvh4q, closest hit, no counters, capped stack, ray queue>
 
 def main():
     with tempfile.TemporaryDirectory() as td:
@@ -35,7 +35,7 @@ def main():
               "VMEM" if o.startswith(("global_", "flat_", "buffer_", "scratch_")) else "LDS" if o.startswith("ds_") else "branch" if o.startswith(("s_cbranch", "s_branch")) else "wait/nop/other"] += 1
         return dict(c)
     allins = [i for _, b in blocks for i in b]
-    print("kernel k_trace_strip<bvh4q, closest, no counters, capped stack>: %d instructions in %d basic blocks" % (len(allins), len(blocks)))
+    print("kernel k_trace_strip<bvh4q, closest, no counters, capped stack, ray queue>: %d instructions in %d basic blocks" % (len(allins), len(blocks)))
     print("  by class:", classes(allins))
     res = re.search(r"^\s*\.vgpr_count:\s*(\d+)", text[m.end():m.end() + 200000], re.M)
     node = max(blocks, key=lambda b: sum(i.startswith("v_cvt_f32_ubyte") for i in b[1]))
