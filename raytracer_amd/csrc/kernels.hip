@@ -1785,7 +1785,8 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         const bool capped = mode == kBvh4q && d_spill && lds_cap >= 2 && s.stack_depth + 2 > (uint32_t)lds_cap;
         const size_t lds_stack = capped ? (size_t)lds_cap * kBlock * sizeof(int) : stack_bytes(s, mode);
         // the staged ray queues sit behind the stacks (BVH4q, ray indices of 32 bits)
-        const bool queue = sc.queue && mode == kBvh4q && n < (1ull << 32);
+        // (a block may ask for 64 KB of dynamic LDS: a stack part that leaves no room for the queues goes without them)
+        const bool queue = sc.queue && mode == kBvh4q && n < (1ull << 32) && lds_stack + kQueueBytesPerBlock <= 64u * 1024u;
         const int q_off = (int)(lds_stack / sizeof(int));
         const size_t lds = lds_stack + (queue ? kQueueBytesPerBlock : 0);
         const uint64_t per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<size_t>(lds, 1)));
