@@ -153,9 +153,9 @@ def main():
     # buffers, so that the kernels of frame k + 1 fill the end of frame k's launches -- the slowest rays of a launch finish with
     # the chip half empty, a fixed ~0.2 ms per frame that is 3 % of a whole frame but a quarter of one rank's share at N = 8.
     # Measured with this loop on one GPU (RT_BENCH_SHARE_OF, scripts/share_bench.sh, profiles/r05l_share_bench.txt): the share of
-    # one rank of 8 takes 0.84 ms per frame with one frame in flight and 0.79-0.80 with two; shares of a half or a quarter of the
-    # frame, and the whole frame, LOSE 1-5 % with two (the launches are long against their tails, and two persistent kernels
-    # side by side take each other's cache), so fewer than 8 ranks keep one.  Two, not three: HIP maps a process's streams onto
+    # one rank of 8 takes 0.81 ms per frame with one frame in flight and 0.76 with two; a quarter of the frame gains 1 %, a half
+    # and the whole frame LOSE 1-3 % with two (the launches are long against their tails, and two persistent kernels side by
+    # side take each other's cache), so fewer than 8 ranks keep one.  Two, not three: HIP maps a process's streams onto
     # 4 hardware queues and a third stream shares its queue with the first (kernel trace: scripts/frames_trace.sh).
     # K timed steps still deliver K complete frames on rank 0.
     F = max(1, int(os.environ.get("RT_BENCH_FRAMES", "2" if (pipelined and stripe_world >= 8) else "1"))) if pipelined else 1
@@ -259,9 +259,11 @@ def main():
     drain()
     ne = len(stages) + 1
     probe = None
-    if F > 1:
-        # per-stage times of single launches: three frames run one at a time, before the timed region (in it the stages of
-        # neighbouring frames overlap, which is the point of F > 1, and events around one stage would time its neighbours too)
+    if F > 1 or stripe_world > 1:
+        # N > 1: per-stage times of single launches from three frames run one at a time BEFORE the timed region, and no event
+        # records in it.  With F > 1 the stages of neighbouring frames overlap there (events around one stage would time its
+        # neighbours too), and on a share of 0.8 ms the five records per step are themselves worth 4 % (share of one rank of 8,
+        # two frames in flight: 0.798 -> 0.762 ms; profiles/r05l_share_bench.txt).  One rank keeps its events in the timed region.
         probe = [[torch.cuda.Event(enable_timing=True) for _ in range(ne)] for _ in range(3)]
         for pe in probe:
             torch.cuda.synchronize()
@@ -279,6 +281,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if probe is not None:                            # N > 1: stage times were taken above; no event records between the launches
+            step()
+            continue
         st_stream = cur_stream()
         ev[k][0].record(st_stream)
         for j, st in enumerate(stages):
@@ -378,7 +383,7 @@ def main():
                   "backend": (dist.get_backend() if grouped else None),          # "nccl" = RCCL over xGMI
                   "exchange": None if not grouped else ("all_gather" if gather_all else "gather to rank 0"),
                   "exchange_overlaps_next_frame": bool(pipelined),
-                  # F > 1: the kernels of successive frames overlap on F streams; the per-stage times below then come from three
+                  # F > 1: the kernels of successive frames overlap on F streams.  N > 1: the per-stage times below come from three
                   # frames run one at a time before the timed region
                   "frames_in_flight": F, "stage_times_from": "timed region" if probe is None else "3 single frames before the timed region"},
         # dynamic LDS of the traversal kernels (a launch argument: profilers show 0): [stack entry][256 threads] ints, and for
