@@ -1843,7 +1843,8 @@ hipError_t noalloc_init(void** out) {                 // the device that is curr
 }
 
 hipError_t launch_trace_noalloc(void* d_scratch, const DevScene& s, int mode, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
-                                hipStream_t st, uint32_t strip, int refill, int lds_cap, bool bin, const BinGrid& grid, uint32_t min_run) {
+                                hipStream_t st, uint32_t strip, int refill, int lds_cap, bool bin, const BinGrid& grid, uint32_t min_run,
+                                bool queue) {
     if (n == 0) return hipSuccess;
     if (!d_scratch || n > kNoAllocMaxRays) return hipErrorInvalidValue;
     unsigned char* base = static_cast<unsigned char*>(d_scratch);
@@ -1851,6 +1852,7 @@ hipError_t launch_trace_noalloc(void* d_scratch, const DevScene& s, int mode, co
     sc.work = reinterpret_cast<unsigned long long*>(base);
     sc.spill = reinterpret_cast<int*>(base + kNoAllocWorkBytes);
     sc.max_blocks = kNoAllocMaxBlocks;
+    sc.queue = queue;                      // the staged ray queue lives in LDS: nothing to allocate
     // the spill slice holds kNoAllocSpillEntries entries per thread: trees that are deeper keep more of the stack in LDS
     const int need = (int)s.stack_depth + 2;
     sc.lds_cap = std::max(lds_cap >= 2 ? lds_cap : need, need - (int)kNoAllocSpillEntries);

@@ -81,7 +81,8 @@ constexpr uint32_t kNoAllocBinBlocks = 256;           // histogram rows of the b
 size_t noalloc_bytes();
 hipError_t noalloc_init(void** d_scratch_out);
 hipError_t launch_trace_noalloc(void* d_scratch, const DevScene& s, int mode, const rt_ray* d_rays, uint64_t n, rt_hit* d_hits,
-                                hipStream_t st, uint32_t strip, int refill, int lds_cap, bool bin, const BinGrid& grid, uint32_t min_run);
+                                hipStream_t st, uint32_t strip, int refill, int lds_cap, bool bin, const BinGrid& grid, uint32_t min_run,
+                                bool queue);
 
 // Capped LDS stack of the strip kernel (kernels.hip "Capped stack"): entries beyond lds_cap spill to global memory,
 // one column per thread of the persistent grid (at most 8 blocks of kThreads per CU).

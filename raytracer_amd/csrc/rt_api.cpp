@@ -884,8 +884,11 @@ int rt_trace_dev_noalloc(rt_ctx* c, int slot, const rt_ray* d_rays, uint64_t n, 
     Replica& r = c->reps[slot];
     RT_HIP(c, hipSetDevice(r.device));
     const int mode = c->mode();
-    RT_HIP(c, launch_trace_noalloc(r.d_noalloc, c->dev_scene(r), mode, d_rays, n, d_hits, (hipStream_t)stream, c->strip, c->refill,
-                                   c->lds_stack, wants_binning(c, mode, n), c->bin_grid, c->binning == 1 ? 0u : kBinMinRun));
+    // at most 2^22 rays: the launches the staged ray queue pays for (trace_rays), with its thresholds unless RT_OPT_REFILL is set
+    const bool queue = c->ray_queue != 0 && mode == kBvh4q;
+    const int refill = queue && c->refill == kDefaultRefill ? (6 | (1 << 8)) : c->refill;
+    RT_HIP(c, launch_trace_noalloc(r.d_noalloc, c->dev_scene(r), mode, d_rays, n, d_hits, (hipStream_t)stream, c->strip, refill,
+                                   c->lds_stack, wants_binning(c, mode, n), c->bin_grid, c->binning == 1 ? 0u : kBinMinRun, queue));
     return RT_OK;
 } RT_ABI_CATCH(c)
 
