@@ -506,6 +506,11 @@ def test_staged_ray_queue_changes_nothing(renderer, torch_dev):
             assert run() == ref, f"queue on, binning {binning}, cap {cap}, refill {refill:#x}, {n} rays"
         renderer.set_option(rt.OPT_LDS_STACK, 20)
         renderer.set_option(rt.OPT_REFILL, 16 | (12 << 8))
+        renderer.set_option(rt.OPT_RAY_BINNING, 0)
+        for strip in (64, 1 << 14):                                   # chunks of one wave's worth, and chunks larger than small buffers
+            renderer.set_option(rt.OPT_STRIP, strip)
+            assert run() == ref, f"queue on, chunks of {strip} rays, {n} rays"
+        renderer.set_option(rt.OPT_STRIP, 256)
         renderer.set_option(rt.OPT_RAY_QUEUE, 2)                      # auto: on for this launch (nothing is binned at this size)
         renderer.set_option(rt.OPT_RAY_BINNING, 2)
         assert run() == ref, "queue auto"
