@@ -128,6 +128,23 @@ __device__ __forceinline__ float safe_rcp(float d) {
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// Ray records in, hit records out: streamed once.  With `nt` (wave-uniform; launches on structures that do not fit the L2s, i.e.
+// the ones whose rays are binned) they go past the caches as nontemporal accesses, so that they do not push nodes and triangles
+// out: 10 M-triangle soup 2.97 -> 3.04 Grays/s at 64 Mi rays, C5 46.4 -> 45.9 ms (profiles/r05j_nontemporal.txt).  Not for
+// structures the L2s hold: the next stage reads the hit records, and finds them in the cache (bench frame: bounce -0.7 %,
+// last segment + resolve +4.5 %, together nothing).
+__device__ __forceinline__ float4 load_stream(const float4* p, bool nt) {
+    if (nt) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+__device__ __forceinline__ void store_stream(float4* p, float4 v, bool nt) {
+    if (nt) __builtin_nontemporal_store((v4f){ v.x, v.y, v.z, v.w }, reinterpret_cast<v4f*>(p));
+    else    *p = v;
+}
 
 // Per-ray slab constants: t = plane * idir + (-o * idir).
 //
@@ -629,6 +646,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                                                         const uint32_t* __restrict__ perm_on /* device flag, null = on */,
                                                         int* __restrict__ spill_base /* CAPPED: [entry][thread of the launch] */, int lds_cap,
                                                         int q_off /* QUEUE: ints from the start of LDS to the ray queues */,
+                                                        int nt_arg /* ray loads and hit stores nontemporal */,
                                                         float4* __restrict__ hits, uint8_t* __restrict__ occ,
                                                         unsigned long long* counters) {
     extern __shared__ int stack[];
@@ -636,6 +654,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
     float4* const qw = reinterpret_cast<float4*>(stack + (QUEUE ? q_off : 0)) + (threadIdx.x >> 6) * (4 * kQueue);   // this wave's queue
     uint32_t q_head = 0, q_avail = 0;                                  // wave-uniform: next slot to hand out, slots left
     uint32_t my32 = 0;                                                 // QUEUE: the ray's index (32 bits)
+    const bool nt = nt_arg != 0;
     const float4* __restrict__ nodes = s.nodes;
     const float4* __restrict__ tris = s.tris;
     if (perm && perm_on && *perm_on == 0u) perm = nullptr;             // launch_bin found the buffer coherent already
@@ -711,7 +730,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                     const uint64_t cand = (uint64_t)chunk * strip + cur + lane;
                     const uint32_t idx = perm ? perm[cand] : (uint32_t)cand;
                     const float4* rp = reinterpret_cast<const float4*>(rays + idx);
-                    const float4 r0 = rp[0], r1 = rp[1];
+                    const float4 r0 = load_stream(rp, nt), r1 = load_stream(rp + 1, nt);
                     const Slab ns = make_slab<MODE>(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), s.ray_pad);
                     qw[lane] = r0;
                     qw[kQueue + lane] = r1;
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
                 const uint64_t cand = (uint64_t)chunk * strip + cur + rank;
                 my = perm ? (uint64_t)perm[cand] : cand;
                 const float4* rp = reinterpret_cast<const float4*>(rays + my);
-                float4 r0 = rp[0], r1 = rp[1];
+                float4 r0 = load_stream(rp, nt), r1 = load_stream(rp + 1, nt);
                 o = mk(r0.x, r0.y, r0.z); d = mk(r1.x, r1.y, r1.z); tmin = r0.w; tmax = r1.w;
                 tmin0 = fmaxf(tmin, 0.0f);
                 b.t = tmax; b.u = 0.0f; b.v = 0.0f; b.key = 0u;
@@ -837,7 +856,7 @@ __global__ __launch_bounds__(kBlock) RT_STRIP_ATTR void k_trace_strip(DevScene s
         if (live && node == kDone && pend == 0) {
             const uint64_t at = QUEUE ? (uint64_t)my32 : my;
             if (ANY) occ[at] = b.t < tmax ? 1 : 0;
-            else     hits[at] = pack_hit(b, tmax);
+            else     store_stream(hits + at, pack_hit(b, tmax), nt);
         }
     }
     if (COUNT) {
@@ -1797,7 +1816,7 @@ hipError_t launch_trace(const DevScene& s, int mode, bool any_hit, bool count, c
         uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + kBlock / 64 - 1) / (kBlock / 64), per_cu * (uint64_t)num_cus()));
         if (sc.max_blocks) blocks = std::min<uint64_t>(blocks, sc.max_blocks);
         dim3 g((uint32_t)blocks);
-#define RT_LAUNCH(M, A, C, P, Q) hipLaunchKernelGGL((k_trace_strip<M, A, C, P, Q>), g, b, lds, st, s, d_rays, n, strip, rf, tth, rf_perm, work, d_perm, d_perm_on, d_spill, lds_cap, q_off, hits, d_occ, d_counters)
+#define RT_LAUNCH(M, A, C, P, Q) hipLaunchKernelGGL((k_trace_strip<M, A, C, P, Q>), g, b, lds, st, s, d_rays, n, strip, rf, tth, rf_perm, work, d_perm, d_perm_on, d_spill, lds_cap, q_off, (int)sc.stream_nt, hits, d_occ, d_counters)
 #define RT_LAUNCH_M(M, P, Q) do { if (any_hit) { if (count) RT_LAUNCH(M, true, true, P, Q); else RT_LAUNCH(M, true, false, P, Q); } \
                                   else         { if (count) RT_LAUNCH(M, false, true, P, Q); else RT_LAUNCH(M, false, false, P, Q); } } while (0)
         if (mode == kBvh4q) {

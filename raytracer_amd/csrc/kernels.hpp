@@ -61,8 +61,9 @@ hipError_t launch_bin(const rt_ray* d_rays, uint64_t n, const BinGrid& g, uint32
 //   lds_cap    stack entries per lane kept in LDS when spill is given
 //   max_blocks bound on the persistent grid (0 = none): the spill area holds one column per thread of the grid
 //   refill_perm  (leaf-vote threshold << 8 | refill threshold) for large buffers that are handed out permuted; 0 = as the others
+//   stream_nt  ray loads and hit stores go past the caches (structures that do not fit the L2s)
 //   queue      BVH4q: staged ray queues in LDS (k_trace_strip<QUEUE>): refills read prepared rays instead of loading and preparing them
-struct StripScratch { unsigned long long* work = nullptr; int* spill = nullptr; int lds_cap = 0; uint32_t max_blocks = 0; int refill_perm = 0; bool queue = false; };
+struct StripScratch { unsigned long long* work = nullptr; int* spill = nullptr; int lds_cap = 0; uint32_t max_blocks = 0; int refill_perm = 0; bool queue = false; bool stream_nt = false; };
 // closest hit for a buffer whose consecutive rays (after d_perm, if given) are coherent: 64 rays per wave walk as one packet
 hipError_t launch_trace_packets(const DevScene& s, bool count, const rt_ray* d_rays, uint64_t n, const uint32_t* d_perm,
                                 rt_hit* d_hits, unsigned long long* d_counters, hipStream_t st);

@@ -335,6 +335,7 @@ hipError_t trace_rays(rt_ctx* c, Replica& r, bool any_hit, bool count, const rt_
         // 8 Mi rays, round 2's tree: L2 hit 52 %, HBM 5.8 TB/s; profiles/r04j_c4_8mi_summary.md) -- 32 entries in LDS, 4 blocks
         // per CU with the queue (r05y_c4_cap.txt; 2 Mi rays +12 %, 4-16 Mi +3-5 % before the queue, r04k_c4_cap_sweep.txt).
         // Explicit RT_OPT_LDS_STACK / RT_OPT_REFILL values hold.
+        sc.stream_nt = bin;                   // structure larger than the L2s: the ray / hit records stream past them (kernels.hip load_stream)
         const bool small_binned = bin && n < (1ull << 25);
         sc.queue = mode == kBvh4q && n < (1ull << 32) && (c->ray_queue == 1 || (c->ray_queue == 2 && (!bin || small_binned)));
         if (c->lds_stack == kDefaultLdsStack) {
