@@ -129,6 +129,7 @@ __device__ __forceinline__ float safe_rcp(float d) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr uint64_t kStreamMinRays = 1ull << 22;     // buffers of this many records and more are taken to outlive the caches
 // Ray records in, hit records out: streamed once.  With `nt` (wave-uniform; launches on structures that do not fit the L2s, i.e.
 // the ones whose rays are binned) they go past the caches as nontemporal accesses, so that they do not push nodes and triangles
 // out: 10 M-triangle soup 2.97 -> 3.04 Grays/s at 64 Mi rays, C5 46.4 -> 45.9 ms (profiles/r05j_nontemporal.txt).  Not for
@@ -1107,11 +1108,15 @@ __device__ __forceinline__ void primary_body(int* stack /* dynamic LDS */, const
         if (hits) hits[r] = hit;
         if (SHADE) {
             if (!PACKET) go = shade_one<MODE>(s, r0, r1, hit, T, C, key, so.seed, so.next != nullptr, stk, no, nd);
-            so.thr[r] = make_float4(T.x, T.y, T.z, 0.0f);
-            so.rad[r] = make_float4(C.x, C.y, C.z, 0.0f);
+            // path state and bounce rays are read again only after the whole frame's worth of them has been written (and the
+            // bounce launch wants the tree in the caches, not them): past the caches when the buffers are large.  Bench frame:
+            // the BOUNCE launch that follows gains 0.8 %, C5's primary pass 1.5 % (profiles/r05j_nontemporal.txt)
+            const bool pnt = (uint64_t)n_waves * 64u >= kStreamMinRays;
+            store_stream(so.thr + r, make_float4(T.x, T.y, T.z, 0.0f), pnt);
+            store_stream(so.rad + r, make_float4(C.x, C.y, C.z, 0.0f), pnt);
             if (so.next) {
-                so.next[2 * r] = go ? make_float4(no.x, no.y, no.z, 0.0f) : make_float4(0, 0, 0, 0);
-                so.next[2 * r + 1] = go ? make_float4(nd.x, nd.y, nd.z, 1e20f) : make_float4(0, 0, 0, 0);
+                store_stream(so.next + 2 * r, go ? make_float4(no.x, no.y, no.z, 0.0f) : make_float4(0, 0, 0, 0), pnt);
+                store_stream(so.next + 2 * r + 1, go ? make_float4(nd.x, nd.y, nd.z, 1e20f) : make_float4(0, 0, 0, 0), pnt);
             }
         }
     } else if (wave < n_waves && x < w && yl < rows) {
@@ -1282,6 +1287,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __re
     extern __shared__ int stack[];
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    // (plain loads and stores: nontemporal, the two 16-byte halves of a 32-byte ray record fetch their line twice, and the kernel
+    // -- HBM-bound on large buffers -- takes 10-25 % longer: profiles/r05j_nontemporal.txt)
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
     float4 r0 = rp[0], r1 = rp[1];
     float4 hit = hits[i];
@@ -1371,12 +1378,13 @@ __global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rt_r
         // Without lights the last segment adds only the emission of what was hit (:313): neither the hit point nor the ray
         // is needed, so the 32-byte rays are not read at all (80 -> 48 bytes per path).  Relies on what every trace kernel
         // of this library guarantees: the hit record of a dead ray (tmax <= tmin) is a miss.
-        const float4 hit = hits[i];
-        const float4 c4 = rad[i];
+        const bool nt = n >= kStreamMinRays;
+        const float4 hit = load_stream(hits + i, nt);
+        const float4 c4 = load_stream(rad + i, nt);
         C = mk(c4.x, c4.y, c4.z);
         const uint32_t prim = __float_as_uint(hit.w);
         if (prim != RT_MISS) {
-            const float4 t4 = thr[i];
+            const float4 t4 = load_stream(thr + i, nt);
             const uint32_t mid = (prim & RT_SPHERE_BIT) ? s.sphere_mat[prim & ~RT_SPHERE_BIT] : __float_as_uint(s.normals[(size_t)prim * 3].w);
             const Mat m = load_mat(s, mid);
             C = mk(__fmaf_rn(t4.x * m.emission.x, m.strength, C.x), __fmaf_rn(t4.y * m.emission.y, m.strength, C.y),
