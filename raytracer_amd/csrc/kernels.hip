@@ -128,6 +128,10 @@ __device__ __forceinline__ float safe_rcp(float d) {
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Streaming kernels want all 8 waves per SIMD: the register allocator is told so (the max-ilp scheduling strategy this file is
+// compiled with otherwise spends registers on overlap they cannot use: k_shade_resolve 55 -> 70 VGPRs, k_path_brute 64 -> 83)
+#define RT_WAVES8 __attribute__((amdgpu_waves_per_eu(8, 8)))
+#define RT_WAVES8_IF(cond) __attribute__((amdgpu_waves_per_eu((cond) ? 8 : 1, 8)))
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr uint64_t kStreamMinRays = 1ull << 22;     // buffers of this many records and more are taken to outlive the caches
 // Ray records in, hit records out: streamed once.  With `nt` (wave-uniform; launches on structures that do not fit the L2s, i.e.
@@ -1164,7 +1168,7 @@ void k_primary_packet(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_
 // traffic of the staged pipeline (192 bytes per path segment between the trace and shade kernels), not by its arithmetic, and
 // with no traversal there is no divergence to manage: a thread keeps ray, throughput and radiance in registers over all bounces
 // and writes 16 bytes at the end.  Same functions in the same order as the stages, hence the same radiance bit for bit.
-__global__ __launch_bounds__(kBlock) void k_path_brute(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
+__global__ __launch_bounds__(kBlock) RT_WAVES8 void k_path_brute(DevScene s, DevCamera cam, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows,
                                                        uint32_t stripe_h, uint32_t stripe_step, uint32_t spp, uint32_t bounces,
                                                        uint32_t seed, float4* __restrict__ rad) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(DevScene s, const rt_ray* __r
 // FIRST: segment 0 of a path -- throughput 1 and radiance 0 are implied (frag.glsl:306-307) instead of read, and both
 // buffers are written for every ray slot, dead ones included (what k_primary<SHADE> does in one kernel).
 template <int MODE, bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
+__global__ __launch_bounds__(kBlock) RT_WAVES8_IF(MODE == kBrute) void k_shade(DevScene s, const rt_ray* __restrict__ rays,
                                                   const float4* __restrict__ hits, uint64_t n, uint32_t key0,
                                                   uint32_t row_len, uint32_t stripe_h, uint32_t stripe_step,
                                                   uint32_t seed, float4* __restrict__ thr, float4* __restrict__ rad,
@@ -1367,7 +1371,7 @@ __device__ __forceinline__ uint32_t to_rgba8(float r, float g, float b) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_shade_resolve(DevScene s, const rt_ray* __restrict__ rays,
+__global__ __launch_bounds__(kBlock) RT_WAVES8_IF(MODE == kBrute) void k_shade_resolve(DevScene s, const rt_ray* __restrict__ rays,
                                                           const float4* __restrict__ hits, uint64_t n, uint32_t spp,
                                                           const float4* __restrict__ thr, const float4* __restrict__ rad,
                                                           float4* __restrict__ lin, uint32_t* __restrict__ rgba) {

@@ -14,7 +14,8 @@ CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
 def makefile_flags():
     text = open(os.path.join(CSRC, "Makefile")).read().replace("\\\n", " ")
     flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", text, re.M).group(1).replace("$(ARCH)", "gfx950").split()
-    return flags
+    kflags = re.search(r"^KFLAGS\s*\??=\s*(.*)$", text, re.M)          # kernels.hip only (scheduling strategy)
+    return flags + (kflags.group(1).split() if kflags else [])
 
 
 def find_overlaps(asm_text):

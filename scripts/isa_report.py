@@ -6,7 +6,7 @@ and reports: instruction totals of the kernel, and per-class histograms + full l
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
-FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize --offload-arch=gfx950".split()
+FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize --offload-arch=gfx950 -mllvm -amdgpu-sched-strategy=max-ilp".split()     # = CXXFLAGS + KFLAGS of the Makefile
 KERNEL = "_ZN2rt12_GLOBAL__N_113k_trace_stripILi3ELb0ELb0ELb1ELb1EEE"     # <bvh4q, closest hit, no counters, capped stack, ray queue>
 
 def main():
